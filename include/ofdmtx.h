@@ -1,0 +1,151 @@
+/*
+ * libofdmtx -- batched 802.11a/g/p OFDM transmit chain on AMD MI355X (gfx950).
+ *
+ * C ABI of the HIP library.  Every pointer named d_* is a DEVICE pointer (HBM of the
+ * context's device); everything else is host memory.  No call allocates or frees caller
+ * buffers.  All functions return 0 on success or a negative OFDMTX_E* code; no exception
+ * crosses this boundary.  A context is bound to one device and is thread-compatible (use
+ * one per device / per host thread).  Kernels are enqueued on the stream passed in
+ * (a hipStream_t passed as void*; NULL = the default stream) and are NOT synchronised.
+ *
+ * What each entry point stands in for in the reference (paths relative to the reference
+ * root, ftw_80211_ofdm_tx/src/...):
+ *   - the SWIG module generated from ftw/ftw.i:42-218 (python "gnuradio.ftw"), i.e. the C++
+ *     blocks ofdm_mapper / ofdm_pilot_cc / ofdm_cmap_cc / ofdm_preamble / zerogap and the
+ *     free function ftw_crc32, plus the GNU Radio blocks wired between them in
+ *     examples/ftw_ofdm.py:98-179 (fft_vcc, ofdm_cyclic_prefixer, multiply_const_cc);
+ *   - the per-packet Python of examples/ftw_packet_utils.py:25-372 that ofdm_mod.send_pkt
+ *     (examples/ftw_ofdm.py:191-219) runs before handing a message to the mapper.
+ */
+#ifndef OFDMTX_H
+#define OFDMTX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OFDMTX_OK 0
+#define OFDMTX_EINVAL (-1)    /* bad argument (NULL, out of range)                          */
+#define OFDMTX_EREGIME (-2)   /* regime not in 1..8 (reference: UnboundLocalError,
+                                 examples/ftw_packet_utils.py:39-78 has no else branch)    */
+#define OFDMTX_ELENGTH (-3)   /* MPDU+FCS > 3168 bytes (reference: ValueError,
+                                 examples/ftw_packet_utils.py:119-121)                     */
+#define OFDMTX_EHIP (-4)      /* a HIP runtime call failed; see ofdmtx_last_hip_error()     */
+#define OFDMTX_ENOMEM (-5)
+#define OFDMTX_ESHAPE (-6)    /* block parameter the reference's blocks reject with
+                                 std::invalid_argument (ftw/ftw_ofdm_pilot_cc.cc:110-111,
+                                 ftw/ftw_ofdm_cmap_cc.cc:97-99, ftw/ftw_ofdm_mapper.cc:61-62) */
+#define OFDMTX_ETOOBIG (-7)   /* batch exceeds the 32-bit row index of the kernels          */
+
+/* plan flags */
+#define OFDMTX_F_PREAMBLE 1u  /* prepend the 4x80-sample preamble (ftw/ftw_ofdm_preamble.cc:79-83) */
+#define OFDMTX_F_ZEROGAP 2u   /* append 13x80 zero samples (ftw/ftw_zerogap.cc:88-92)              */
+#define OFDMTX_F_SWAPIQ 4u    /* swap re/im (examples/ftw_ofdm.py:155-163)                         */
+
+/* pilot polarity index of symbol s of packet q */
+#define OFDMTX_PILOT_REF_STREAM 0 /* running counter over the whole stream, as the reference's
+                                     process-global counter does (ftw/ftw_ofdm_pilot_cc.cc:82,159):
+                                     pilot_start + sum_{r<q}(N_sym_r+1) + s                        */
+#define OFDMTX_PILOT_PER_PACKET 1 /* restart at pilot_start for every packet (the standard)        */
+
+typedef struct ofdmtx_ctx ofdmtx_ctx;
+typedef struct ofdmtx_plan ofdmtx_plan;
+
+/* Geometry of one packet -- the numbers get_info/ftw_make derive
+ * (examples/ftw_packet_utils.py:81-97,160-171,193). */
+typedef struct ofdmtx_pkt_info {
+    int32_t n_cbps, n_bpsc, n_dbps;
+    int32_t n_sym;        /* DATA symbols                                       */
+    int32_t n_data, n_pad;
+    int32_t txtime;       /* microseconds, goes into the MAC duration field     */
+    int32_t length;       /* MPDU + FCS bytes = SIGNAL LENGTH                   */
+    int32_t plcp_len;     /* bytes entering the scrambler                       */
+    int32_t msg_len;      /* bytes of the mapper message = 6 + N_sym*N_cbps/8   */
+    int32_t n_rows;       /* 80-sample rows with the plan flags applied         */
+} ofdmtx_pkt_info;
+
+/* Totals and strides of a plan.  Tap/message buffers use 16-byte aligned per-packet
+ * strides chosen by the library; the IQ buffer is densely packed (rows of 80 complex64). */
+typedef struct ofdmtx_plan_sizes {
+    uint64_t n_pkts;
+    uint64_t payload_bytes;   /* extent of the payload buffer the plan reads                 */
+    uint64_t plcp_bytes;      /* size of a plcp / scrambled tap buffer                       */
+    uint64_t msg_bytes;       /* size of a coded / interleaved (mapper message) buffer       */
+    uint64_t n_symbols;       /* sum of (1 + N_sym): rows of a `mapped` tap (48 complex64)   */
+    uint64_t n_rows;          /* 80-sample rows of the IQ buffer                             */
+    uint64_t n_samples;       /* = 80 * n_rows complex64                                     */
+} ofdmtx_plan_sizes;
+
+const char *ofdmtx_strerror(int code);
+int ofdmtx_last_hip_error(void);   /* hipError_t of the last failing HIP call on this thread */
+
+/* ---- context ---------------------------------------------------------------------- */
+int ofdmtx_create(int device, ofdmtx_ctx **out);
+int ofdmtx_destroy(ofdmtx_ctx *ctx);
+
+/* Replace the constellation used for DATA symbols with n_bpsc bits per carrier
+ * (n = 2^n_bpsc complex points, re/im interleaved, index = bits MSB first) -- the
+ * `constellation` argument of ftw.ofdm_mapper (ftw/ftw.i:157-163).  The SIGNAL symbol always
+ * uses the fixed BPSK {-1,+1} (ftw/ftw_ofdm_mapper.cc:179,238-240). */
+int ofdmtx_set_constellation(ofdmtx_ctx *ctx, int n_bpsc, const float *re_im, int n);
+
+/* ---- host helpers ----------------------------------------------------------------- */
+/* ftw.ftw_crc32 (ftw/ftw_crc32.cc:72-82): bit-reversed reflected CRC-32. */
+uint32_t ofdmtx_crc32(const uint8_t *buf, size_t len);
+/* get_info (examples/ftw_packet_utils.py:25-105) for payload_len bytes behind the 24-byte
+ * MAC header.  flags as for plans (they only affect n_rows). */
+int ofdmtx_packet_info(int regime, int payload_len, double symbol_time, unsigned flags,
+                       ofdmtx_pkt_info *out);
+
+/* ---- plans -------------------------------------------------------------------------
+ * A plan fixes the batch geometry: per packet regime and payload length, where each
+ * packet's bytes and samples live, pilot indexing, output framing and amplitude
+ * (tx_amplitude of examples/ftw_ofdm_tx_uhd.py:82-86; 1/sqrt(64) of examples/ftw_ofdm.py:126
+ * is always applied to symbol rows). */
+int ofdmtx_plan_uniform(ofdmtx_ctx *ctx, uint64_t n_pkts, int regime, uint32_t payload_len,
+                        uint64_t payload_stride, double symbol_time, int pilot_mode,
+                        uint32_t pilot_start, unsigned flags, float amp, ofdmtx_plan **out);
+/* Ragged / mixed-rate batch.  regimes[n], payload_len[n], payload_off[n] (byte offset of each
+ * payload in the payload buffer; NULL = densely packed in order) are host arrays. */
+int ofdmtx_plan_ragged(ofdmtx_ctx *ctx, uint64_t n_pkts, const uint8_t *regimes,
+                       const uint32_t *payload_len, const uint64_t *payload_off,
+                       double symbol_time, int pilot_mode, uint32_t pilot_start, unsigned flags,
+                       float amp, ofdmtx_plan **out);
+int ofdmtx_plan_destroy(ofdmtx_plan *plan);
+int ofdmtx_plan_get_sizes(const ofdmtx_plan *plan, ofdmtx_plan_sizes *out);
+/* Per-packet layout, host arrays of n_pkts entries each (any may be NULL):
+ * plcp_off / msg_off byte offsets into tap / message buffers, sym_off index of the packet's
+ * SIGNAL symbol in a `mapped` tap, sample_off index of the packet's first complex sample,
+ * n_sym DATA symbols, pilot_base polarity index of the packet's SIGNAL symbol. */
+int ofdmtx_plan_get_layout(const ofdmtx_plan *plan, uint64_t *plcp_off, uint64_t *msg_off,
+                           uint64_t *sym_off, uint64_t *sample_off, uint32_t *n_sym,
+                           uint32_t *plcp_len, uint32_t *msg_len, uint32_t *pilot_base);
+
+/* ---- kernels ---------------------------------------------------------------------- */
+/* Bit-level chain of ofdm_mod.send_pkt for every packet of the plan
+ * (examples/ftw_ofdm.py:201-217): ftw_make -> scrambler -> conv_encoder -> interleaver.
+ * d_interleaved receives the mapper messages; the other outputs are optional taps
+ * (NULL = not written): d_plcp = ftw_make output, d_scrambled, d_coded. */
+int ofdmtx_encode_bits(ofdmtx_ctx *ctx, const ofdmtx_plan *plan, const uint8_t *d_payloads,
+                       uint8_t *d_plcp, uint8_t *d_scrambled, uint8_t *d_coded,
+                       uint8_t *d_interleaved, void *stream);
+
+/* Symbol-level flowgraph mapper -> pilot -> cmap -> IFFT -> CP -> scale -> preamble ->
+ * zerogap -> amplitude (examples/ftw_ofdm.py:175-179, examples/ftw_ofdm_tx_uhd.py:86), fused.
+ * d_msg: mapper messages in plan layout.  d_mapped (optional tap): n_symbols x 48 complex64,
+ * the mapper block's output.  d_iq: n_samples complex64 (re,im float32 pairs). */
+int ofdmtx_modulate(ofdmtx_ctx *ctx, const ofdmtx_plan *plan, const uint8_t *d_msg,
+                    float *d_mapped, float *d_iq, void *stream);
+
+/* payload -> IQ for the whole batch (send_pkt + flowgraph).  d_work: scratch of
+ * ofdmtx_plan_sizes.msg_bytes bytes. */
+int ofdmtx_tx(ofdmtx_ctx *ctx, const ofdmtx_plan *plan, const uint8_t *d_payloads,
+              uint8_t *d_work, float *d_iq, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OFDMTX_H */

@@ -1,0 +1,100 @@
+"""ctypes binding of libofdmtx.so (the HIP library; see include/ofdmtx.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails, an exception is
+raised.  The library is built in-tree by ofdm_amd/csrc/Makefile (`python -c "import
+__graft_entry__ as g; g.build()"`).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libofdmtx.so")
+
+OK = 0
+EINVAL, EREGIME, ELENGTH, EHIP, ENOMEM, ESHAPE, ETOOBIG = -1, -2, -3, -4, -5, -6, -7
+F_PREAMBLE, F_ZEROGAP, F_SWAPIQ = 1, 2, 4
+PILOT_REF_STREAM, PILOT_PER_PACKET = 0, 1
+
+
+class OfdmTxError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, "libofdmtx: %s (code %d)" % (msg, code))
+        self.code = code
+
+
+class PktInfo(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_cbps", "n_bpsc", "n_dbps", "n_sym", "n_data", "n_pad",
+                                          "txtime", "length", "plcp_len", "msg_len", "n_rows")]
+
+
+class PlanSizes(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("n_pkts", "payload_bytes", "plcp_bytes", "msg_bytes",
+                                           "n_symbols", "n_rows", "n_samples")]
+
+
+# name -> (restype, argtypes); must list every function include/ofdmtx.h declares
+_VP = C.c_void_p
+PROTOTYPES = {
+    "ofdmtx_strerror": (C.c_char_p, [C.c_int]),
+    "ofdmtx_last_hip_error": (C.c_int, []),
+    "ofdmtx_create": (C.c_int, [C.c_int, C.POINTER(_VP)]),
+    "ofdmtx_destroy": (C.c_int, [_VP]),
+    "ofdmtx_set_constellation": (C.c_int, [_VP, C.c_int, _VP, C.c_int]),
+    "ofdmtx_crc32": (C.c_uint32, [C.c_char_p, C.c_size_t]),
+    "ofdmtx_packet_info": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_uint, C.POINTER(PktInfo)]),
+    "ofdmtx_plan_uniform": (C.c_int, [_VP, C.c_uint64, C.c_int, C.c_uint32, C.c_uint64, C.c_double,
+                                      C.c_int, C.c_uint32, C.c_uint, C.c_float, C.POINTER(_VP)]),
+    "ofdmtx_plan_ragged": (C.c_int, [_VP, C.c_uint64, _VP, _VP, _VP, C.c_double, C.c_int, C.c_uint32,
+                                     C.c_uint, C.c_float, C.POINTER(_VP)]),
+    "ofdmtx_plan_destroy": (C.c_int, [_VP]),
+    "ofdmtx_plan_get_sizes": (C.c_int, [_VP, C.POINTER(PlanSizes)]),
+    "ofdmtx_plan_get_layout": (C.c_int, [_VP] * 9),
+    "ofdmtx_encode_bits": (C.c_int, [_VP] * 8),
+    "ofdmtx_modulate": (C.c_int, [_VP] * 6),
+    "ofdmtx_tx": (C.c_int, [_VP] * 6),
+}
+
+_lib = None
+
+
+def load():
+    """Load the library once; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OfdmTxError(EINVAL, "%s not found -- build it with ofdm_amd/csrc/Makefile "
+                                  "(there is no CPU fallback)" % LIB_PATH)
+    # PyTorch ships its own HIP runtime (same soname); import it first so that this library
+    # binds to the runtime torch's tensors and streams live in instead of loading a second one.
+    import torch  # noqa: F401
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != OK:
+        lib = load()
+        msg = lib.ofdmtx_strerror(rc).decode()
+        if rc == EHIP:
+            msg += " (hipError %d)" % lib.ofdmtx_last_hip_error()
+        if rc == ELENGTH:
+            raise ValueError("MPDU-length must be in [0, 3168]")      # ftw_packet_utils.py:119-121
+        raise OfdmTxError(rc, msg)
+
+
+def packet_info(regime, payload_len, symbol_time=4.0, flags=F_PREAMBLE | F_ZEROGAP):
+    info = PktInfo()
+    check(load().ofdmtx_packet_info(int(regime), int(payload_len), float(symbol_time), int(flags),
+                                    C.byref(info)))
+    return info
+
+
+def crc32(data):
+    data = bytes(data)
+    return load().ofdmtx_crc32(data, len(data))

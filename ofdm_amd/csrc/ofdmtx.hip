@@ -1,0 +1,977 @@
+// libofdmtx: batched 802.11a OFDM transmit chain for gfx950 (MI355X).
+//
+// Two kernels cover the path:
+//   k_encode_bits : payload -> PLCP bytes -> scrambler -> K=7 conv. encoder + puncture ->
+//                   interleaver (one wavefront per packet, bits staged in LDS)
+//   k_modulate    : mapper message -> constellation + pilots + carrier map -> 64-point
+//                   inverse FFT (radix 8x8, eight lanes per OFDM symbol) -> cyclic prefix,
+//                   scale, preamble / zero-gap rows -> fully coalesced 16-byte stores
+// The output of a batch is one dense stream of 80-sample rows (640 B each); a wavefront
+// produces eight consecutive rows = 5 KiB of contiguous IQ per iteration.
+//
+// Reference behaviour restated here is cited as file:line relative to the reference root
+// (pu = ftw_80211_ofdm_tx/src/examples/ftw_packet_utils.py, ftw/ = ftw_80211_ofdm_tx/src/ftw/).
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "ofdm_tables.h"
+#include "ofdmtx.h"
+
+namespace {
+
+thread_local int g_last_hip = 0;
+
+#define HIPCHK(expr)                                  \
+    do {                                              \
+        hipError_t e_ = (expr);                       \
+        if (e_ != hipSuccess) {                       \
+            g_last_hip = (int)e_;                     \
+            return OFDMTX_EHIP;                       \
+        }                                             \
+    } while (0)
+
+constexpr int MAXLEN = 3168;          // pu:119
+constexpr int MAX_PLCP = 3264;        // 5 + 3168 + 28 tail/pad bytes, rounded up to 64
+constexpr int SYM_LEN = 80;           // examples/ftw_ofdm.py:75
+constexpr int PRE_ROWS = 4;           // ftw/ftw_ofdm_preamble.cc:79
+constexpr int GAP_ROWS = 13;          // ftw/ftw_zerogap.cc:88
+constexpr int LUT_SIZE = 88;          // [0,2) SIGNAL BPSK, then bpsk@2 qpsk@4 qam16@8 qam64@24
+
+struct RegimeInfo {
+    int n_cbps, n_bpsc, n_dbps, rate_bits, punct, lut_off;   // punct: 0 none, 1 = 3/4, 2 = 2/3
+};
+
+// pu:39-78 (modulation / rate), pu:81 (N_dbps), pu:129-144 (RATE nibble)
+__host__ __device__ inline RegimeInfo regime_info(int regime)
+{
+    switch (regime) {
+    case 1: return {48, 1, 24, 0x0D, 0, 2};
+    case 2: return {48, 1, 36, 0x0F, 1, 2};
+    case 3: return {96, 2, 48, 0x05, 0, 4};
+    case 4: return {96, 2, 72, 0x07, 1, 4};
+    case 5: return {192, 4, 96, 0x09, 0, 8};
+    case 6: return {192, 4, 144, 0x0B, 1, 8};
+    case 7: return {288, 6, 192, 0x01, 2, 24};
+    default: return {288, 6, 216, 0x03, 1, 24};
+    }
+}
+
+// Per-packet record of a ragged plan (device array).
+struct PktRec {
+    uint64_t pay_off;
+    uint64_t plcp_off;
+    uint64_t msg_off;
+    uint32_t sym_off;      // index of the SIGNAL symbol among all symbols of the batch
+    uint32_t pay_len;
+    uint32_t n_sym;
+    uint32_t pilot_base;
+    uint16_t txtime;
+    uint8_t regime;
+    uint8_t pad_;
+    uint32_t pad2_;
+};
+
+// Passed by value to the kernels.
+struct PlanParams {
+    uint32_t n_pkts;
+    uint32_t uniform;
+    // uniform batches: closed forms
+    uint32_t regime, pay_len, n_sym, txtime;
+    uint64_t pay_stride;
+    uint32_t plcp_stride, msg_stride, rows_per_pkt;
+    uint32_t pilot_mode, pilot_start;
+    // ragged batches
+    const PktRec *recs;
+    const uint32_t *row_start;    // n_pkts + 1
+    const uint32_t *group_pkt;    // packet holding the first row of every 8-row group
+    uint32_t total_rows;
+    uint32_t flags;
+    float amp;
+};
+
+struct DevTables {
+    const uint32_t *scr_word;   // 127
+    const float2 *lut;          // LUT_SIZE
+    const float2 *preamble;     // 320
+    const float2 *tw64;         // 64
+    uint32_t pilot_neg[4];
+};
+
+struct Pkt {
+    uint64_t pay_off, plcp_off, msg_off;
+    uint32_t sym_off, pay_len, n_sym, pilot_base, txtime, regime;
+};
+
+template <bool UNIFORM>
+__device__ inline Pkt load_pkt(const PlanParams &P, uint32_t p)
+{
+    Pkt k;
+    if (UNIFORM) {
+        k.pay_off = (uint64_t)p * P.pay_stride;
+        k.plcp_off = (uint64_t)p * P.plcp_stride;
+        k.msg_off = (uint64_t)p * P.msg_stride;
+        k.sym_off = p * (P.n_sym + 1);
+        k.pay_len = P.pay_len;
+        k.n_sym = P.n_sym;
+        k.pilot_base = P.pilot_mode == OFDMTX_PILOT_REF_STREAM
+                           ? (uint32_t)((P.pilot_start + (uint64_t)p * (P.n_sym + 1)) % 127u)
+                           : P.pilot_start % 127u;
+        k.txtime = P.txtime;
+        k.regime = P.regime;
+    } else {
+        const PktRec r = P.recs[p];
+        k.pay_off = r.pay_off;
+        k.plcp_off = r.plcp_off;
+        k.msg_off = r.msg_off;
+        k.sym_off = r.sym_off;
+        k.pay_len = r.pay_len;
+        k.n_sym = r.n_sym;
+        k.pilot_base = r.pilot_base;
+        k.txtime = r.txtime;
+        k.regime = r.regime;
+    }
+    return k;
+}
+
+// Lanes of one wavefront exchange data through LDS without a workgroup barrier: LDS
+// operations of a wave execute in program order, so only the compiler has to be kept from
+// moving accesses across the hand-over point.
+__device__ inline void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ======================================================================================
+// Bit-level kernel
+// ======================================================================================
+
+// MAC header of pu:28-36 (duration bytes 2,3 filled per packet, pu:91)
+__device__ const uint8_t MAC_HDR[24] = {0x08, 0x00, 0x00, 0x00, 0x00, 0x60, 0x08, 0xcd,
+                                        0x37, 0xa6, 0x00, 0x20, 0xd6, 0x01, 0x3c, 0xf1,
+                                        0x00, 0x60, 0x08, 0xad, 0x3b, 0xaf, 0x00, 0x00};
+
+constexpr uint32_t CRC_POLY = 0xEDB88320u;   // ftw/ftw_crc32.cc:45
+
+// a(x) * b(x) mod P(x) in the reflected representation (x^0 = bit 31)
+__device__ inline uint32_t crc_mulmod(uint32_t a, uint32_t b)
+{
+    uint32_t p = 0;
+#pragma unroll 1
+    for (int i = 0; i < 32; i++) {
+        p ^= b & (0u - ((a >> 31) & 1u));
+        a <<= 1;
+        b = (b >> 1) ^ (CRC_POLY & (0u - (b & 1u)));
+    }
+    return p;
+}
+
+// Coded bit with absolute index P (0 = first SIGNAL coded bit) from the scrambled stream
+// held as MSB-first 32-bit words: pu:287-307, g0 = 133o -> even index, g1 = 171o -> odd.
+__device__ inline uint32_t coded_bit(const uint32_t *U, uint32_t P)
+{
+    uint32_t n = P >> 1;
+    uint32_t w = n >> 5;
+    uint32_t sh = 31u - (n & 31u);
+    uint64_t X = ((uint64_t)(w ? U[w - 1] : 0u) << 32) | U[w];
+    uint32_t win = (uint32_t)(X >> sh) & 0x7Fu;          // bit d = u[n-d]
+    return __popc(win & ((P & 1u) ? 0x4Fu : 0x6Du)) & 1u;
+}
+
+// Index into the coded DATA stream of punctured index q: pu:309-341
+template <int PUNCT>
+__device__ inline uint32_t unpuncture(uint32_t q)
+{
+    if (PUNCT == 1) {
+        uint32_t r = q & 3u;
+        return 6u * (q >> 2) + (r == 3u ? 5u : r);
+    }
+    if (PUNCT == 2) return 4u * (q / 3u) + q % 3u;
+    return q;
+}
+
+// Source position k (before interleaving) of interleaved position j within a symbol of N
+// coded bits: inverse of pu:241-253 followed by pu:267-273.
+template <int NBPSC>
+__device__ inline uint32_t deinterleave_pos(uint32_t j)
+{
+    constexpr uint32_t R = 3u * NBPSC;                 // N_cbps / 16
+    constexpr uint32_t S = NBPSC / 2 > 1 ? NBPSC / 2 : 1;
+    uint32_t c = j / R, u = j % R;
+    uint32_t r = S * (u / S) + ((u % S) + c) % S;
+    return 16u * r + c;
+}
+
+template <int NBPSC, int PUNCT>
+__device__ inline void emit_message_bits(const uint32_t *U, uint32_t n_sym, uint8_t *cod_out,
+                                         uint8_t *itl_out, int lane)
+{
+    constexpr uint32_t N = 48u * NBPSC;
+    const uint32_t msg_bits = 48u + n_sym * N;
+    const uint32_t my = 8u * (lane >> 3) + 7u - (lane & 7u);   // ballot bit `lane` = stream bit `my`
+    for (uint32_t j0 = 0; j0 < msg_bits; j0 += 64) {
+        uint32_t j = j0 + my;
+        uint32_t bi = 0, bc = 0;
+        if (j < msg_bits) {
+            if (j < 48u) {
+                bc = coded_bit(U, j);
+                bi = coded_bit(U, deinterleave_pos<1>(j));      // SIGNAL: N = 48, first permutation only
+            } else {
+                uint32_t jj = j - 48u;
+                uint32_t s = jj / N, pos = jj % N;
+                bc = cod_out ? coded_bit(U, 48u + unpuncture<PUNCT>(jj)) : 0u;
+                bi = coded_bit(U, 48u + unpuncture<PUNCT>(s * N + deinterleave_pos<NBPSC>(pos)));
+            }
+        }
+        unsigned long long mi = __ballot(bi);
+        if (lane == 0) *reinterpret_cast<unsigned long long *>(itl_out + (j0 >> 3)) = mi;
+        if (cod_out) {
+            unsigned long long mc = __ballot(bc);
+            if (lane == 0) *reinterpret_cast<unsigned long long *>(cod_out + (j0 >> 3)) = mc;
+        }
+    }
+}
+
+constexpr int ENC_WAVES = 4;
+
+template <bool UNIFORM>
+__global__ void __launch_bounds__(64 * ENC_WAVES)
+k_encode_bits(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads,
+              uint8_t *__restrict__ plcp_out, uint8_t *__restrict__ scr_out,
+              uint8_t *__restrict__ cod_out, uint8_t *__restrict__ itl_out)
+{
+    __shared__ __align__(16) uint8_t s_img[ENC_WAVES][MAX_PLCP + 16];
+    __shared__ __align__(16) uint32_t s_u[ENC_WAVES][MAX_PLCP / 4 + 4];
+    __shared__ uint32_t s_scr[127];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 127; i += 64 * ENC_WAVES) s_scr[i] = T.scr_word[i];
+    __syncthreads();
+
+    uint8_t *img = s_img[wave];
+    uint32_t *U = s_u[wave];
+
+    for (uint32_t p = blockIdx.x * ENC_WAVES + wave; p < P.n_pkts; p += gridDim.x * ENC_WAVES) {
+        const Pkt k = load_pkt<UNIFORM>(P, p);
+        const RegimeInfo ri = regime_info((int)k.regime);
+        const uint32_t mpdu_len = 24u + k.pay_len;
+        const uint32_t length = mpdu_len + 4u;                                   // pu:193
+        const uint32_t n_pad = k.n_sym * ri.n_dbps - (54u + 8u * mpdu_len);      // pu:97
+        const uint32_t plcp_len = 5u + length + (n_pad + 13u) / 8u;              // pu:160-171
+        const uint32_t n_words = (plcp_len + 3u) / 4u;
+
+        // ---- MPDU in natural byte order at img[5..] (pu:100)
+        for (uint32_t i = lane; i < mpdu_len; i += 64) {
+            uint8_t b;
+            if (i < 24u) {
+                b = MAC_HDR[i];
+                if (i == 2u) b = (uint8_t)(k.txtime >> 8);
+                if (i == 3u) b = (uint8_t)k.txtime;
+            } else {
+                b = payloads[k.pay_off + (i - 24u)];
+            }
+            img[5u + i] = b;
+        }
+        wave_sync();
+
+        // ---- CRC-32 over the natural-order MPDU (ftw/ftw_crc32.cc:52-57): every lane takes a
+        // right-aligned chunk of c bytes, chunks are merged with multiplications by x^(8c*2^s).
+        const uint32_t c = (mpdu_len + 63u) / 64u;
+        const int start = (int)mpdu_len - (64 - lane) * (int)c;
+        uint32_t st = (start <= 0 && start + (int)c > 0) ? 0xFFFFFFFFu : 0u;
+        for (int j = start < 0 ? 0 : start; j < start + (int)c; j++) {
+            st ^= img[5 + j];
+#pragma unroll
+            for (int b = 0; b < 8; b++) st = (st >> 1) ^ (CRC_POLY & (0u - (st & 1u)));
+        }
+        uint32_t mul = 0x80000000u;                       // x^0
+        for (uint32_t i = 0; i < 8u * c; i++) mul = (mul >> 1) ^ (CRC_POLY & (0u - (mul & 1u)));
+#pragma unroll 1
+        for (int s = 0; s < 6; s++) {
+            uint32_t left = __shfl(st, lane - (1 << s));
+            uint32_t merged = crc_mulmod(mul, left) ^ st;
+            if ((lane & ((2 << s) - 1)) == ((2 << s) - 1)) st = merged;
+            mul = crc_mulmod(mul, mul);
+        }
+        // final state bit-reversed, then ^0xFFFFFFFF (ftw/ftw_crc32.cc:58-63,75)
+        const uint32_t fcs = __brev(__shfl(st, 63)) ^ 0xFFFFFFFFu;
+
+        // ---- PLCP image: SIGNAL, SERVICE, bit-reversed MPDU, FCS, tail/pad (pu:128-205)
+        for (uint32_t i = lane; i < mpdu_len; i += 64)
+            img[5u + i] = (uint8_t)(__brev((uint32_t)img[5u + i]) >> 24);       // pu:208-218
+        if (lane == 0) {
+            uint32_t rev = __brev(length) >> 20;                                 // pu:147-150
+            uint32_t par = (__popc(rev & 0xFFFu) + __popc((uint32_t)ri.rate_bits)) & 1u;   // pu:153-157
+            uint32_t field = ((uint32_t)ri.rate_bits << 20) | ((rev & 0xFFFu) << 7) | (par << 6);
+            img[0] = (uint8_t)(field >> 16);
+            img[1] = (uint8_t)(field >> 8);
+            img[2] = (uint8_t)field;
+            img[3] = 0;
+            img[4] = 0;                                                          // SERVICE pu:183
+            img[5u + mpdu_len + 0] = (uint8_t)(fcs >> 24);                       // pu:372 ">I"
+            img[5u + mpdu_len + 1] = (uint8_t)(fcs >> 16);
+            img[5u + mpdu_len + 2] = (uint8_t)(fcs >> 8);
+            img[5u + mpdu_len + 3] = (uint8_t)fcs;
+        }
+        for (uint32_t i = 5u + length + lane; i < 4u * n_words + 4u; i += 64) img[i] = 0;
+        wave_sync();
+
+        if (plcp_out)
+            for (uint32_t i = lane; i < plcp_len; i += 64) plcp_out[k.plcp_off + i] = img[i];
+
+        // ---- scrambler on MSB-first words (pu:344-367)
+        const uint32_t tz = 40u + 8u * length;            // first tail bit
+        for (uint32_t w = lane; w <= n_words; w += 64) {
+            uint32_t v = __builtin_bswap32(reinterpret_cast<const uint32_t *>(img)[w]);
+            if (w == 0)
+                v ^= s_scr[0] >> 24;                      // bits 24..31 are SERVICE bits 0..7
+            else
+                v ^= s_scr[(32u * w - 24u) % 127u];
+            if (w == (tz >> 5)) v &= ~(0x3Fu << (26u - (tz & 31u)));   // six tail bits to 0, pu:361-362
+            U[w] = v;
+        }
+        wave_sync();
+
+        if (scr_out)
+            for (uint32_t i = lane; i < plcp_len; i += 64)
+                scr_out[k.plcp_off + i] = (uint8_t)(U[i >> 2] >> (24u - 8u * (i & 3u)));
+
+        // ---- encoder + puncture + interleaver, 64 message bits per step
+        uint8_t *co = cod_out ? cod_out + k.msg_off : nullptr;
+        uint8_t *io = itl_out + k.msg_off;
+        switch (k.regime) {
+        case 1: emit_message_bits<1, 0>(U, k.n_sym, co, io, lane); break;
+        case 2: emit_message_bits<1, 1>(U, k.n_sym, co, io, lane); break;
+        case 3: emit_message_bits<2, 0>(U, k.n_sym, co, io, lane); break;
+        case 4: emit_message_bits<2, 1>(U, k.n_sym, co, io, lane); break;
+        case 5: emit_message_bits<4, 0>(U, k.n_sym, co, io, lane); break;
+        case 6: emit_message_bits<4, 1>(U, k.n_sym, co, io, lane); break;
+        case 7: emit_message_bits<6, 2>(U, k.n_sym, co, io, lane); break;
+        default: emit_message_bits<6, 1>(U, k.n_sym, co, io, lane); break;
+        }
+        wave_sync();
+    }
+}
+
+// ======================================================================================
+// Symbol-level kernel
+// ======================================================================================
+
+__device__ inline float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ inline float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ inline float2 cmul(float2 a, float2 b)
+{
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ inline float2 mul_i(float2 a) { return make_float2(-a.y, a.x); }   // * (+j)
+
+// y[p] = sum_m x[m] e^{+j 2 pi m p / 8}, in place
+__device__ inline void idft8(float2 (&x)[8])
+{
+    const float h = 0.70710678118654752440f;
+    float2 a0 = cadd(x[0], x[4]), a1 = csub(x[0], x[4]);
+    float2 a2 = cadd(x[2], x[6]), a3 = csub(x[2], x[6]);
+    float2 a4 = cadd(x[1], x[5]), a5 = csub(x[1], x[5]);
+    float2 a6 = cadd(x[3], x[7]), a7 = csub(x[3], x[7]);
+    float2 b0 = cadd(a0, a2), b2 = csub(a0, a2);
+    float2 b1 = cadd(a1, mul_i(a3)), b3 = csub(a1, mul_i(a3));
+    float2 b4 = cadd(a4, a6), b6 = csub(a4, a6);
+    float2 b5 = cadd(a5, mul_i(a7)), b7 = csub(a5, mul_i(a7));
+    float2 w5 = make_float2(h * (b5.x - b5.y), h * (b5.x + b5.y));      // b5 * e^{+j pi/4}
+    float2 w7 = make_float2(-h * (b7.x + b7.y), h * (b7.x - b7.y));     // b7 * e^{+j 3pi/4}
+    float2 w6 = mul_i(b6);
+    x[0] = cadd(b0, b4); x[4] = csub(b0, b4);
+    x[1] = cadd(b1, w5); x[5] = csub(b1, w5);
+    x[2] = cadd(b2, w6); x[6] = csub(b2, w6);
+    x[3] = cadd(b3, w7); x[7] = csub(b3, w7);
+}
+
+// What FFT bin k carries: ftw/ftw_ofdm_pilot_cc.cc:119-155 then ftw/ftw_ofdm_cmap_cc.cc:102-107.
+//   >= 0 : data carrier index 0..47;  -1 : null;  -2 : pilot with +p;  -3 : pilot with -p
+__device__ inline int bin_code(int k)
+{
+    int f = k < 32 ? k : k - 64;
+    if (f == 0 || f > 26 || f < -26) return -1;
+    if (f == -21 || f == -7 || f == 7) return -2;
+    if (f == 21) return -3;
+    int t = f + 26;
+    return t - (t > 5) - (t > 19) - (t > 26) - (t > 33) - (t > 47);
+}
+
+constexpr int MOD_WAVES = 4;
+
+template <bool UNIFORM>
+__global__ void __launch_bounds__(64 * MOD_WAVES)
+k_modulate(PlanParams P, DevTables T, const uint8_t *__restrict__ msg, float2 *__restrict__ mapped,
+           float2 *__restrict__ iq)
+{
+    __shared__ float2 s_lut[LUT_SIZE];
+    __shared__ float2 s_pre[PRE_ROWS * SYM_LEN];
+    __shared__ __align__(16) float2 s_buf[MOD_WAVES][8 * SYM_LEN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float amp = P.amp;
+    for (int i = tid; i < LUT_SIZE; i += 64 * MOD_WAVES) s_lut[i] = T.lut[i];
+    for (int i = tid; i < PRE_ROWS * SYM_LEN; i += 64 * MOD_WAVES) {
+        float2 v = T.preamble[i];                         // pu:508 literals as float32 ...
+        s_pre[i] = make_float2(v.x * amp, v.y * amp);     // ... times tx_amplitude
+    }
+    __syncthreads();
+
+    const int l = lane & 7, g = lane >> 3;
+    float2 *buf = s_buf[wave];
+    const float scale = 0.125f * amp;   // 1/sqrt(64) is a power of two: (x*0.125)*amp == x*(0.125*amp)
+
+    float2 tw[8];
+#pragma unroll
+    for (int p = 0; p < 8; p++) tw[p] = T.tw64[(l * p) & 63];
+
+    // the lane's own eight consecutive bins 8l..8l+7 (mapping stage)
+    int code[8];
+    int d0 = -1, cnt = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        code[i] = bin_code(8 * l + i);
+        if (code[i] >= 0) {
+            if (d0 < 0) d0 = code[i];
+            cnt++;
+        }
+    }
+    (void)cnt;
+
+    const uint32_t pre_rows = (P.flags & OFDMTX_F_PREAMBLE) ? PRE_ROWS : 0;
+    const uint32_t n_groups = (P.total_rows + 7u) / 8u;
+
+    for (uint32_t grp = blockIdx.x * MOD_WAVES + wave; grp < n_groups; grp += gridDim.x * MOD_WAVES) {
+        const uint32_t row = grp * 8u + g;
+        // ---- which packet / which row of it
+        int type = 3;                                     // 0 preamble, 1 symbol, 2 gap, 3 beyond the end
+        uint32_t pkt = 0, r = 0;
+        Pkt k = {};
+        if (row < P.total_rows) {
+            if (UNIFORM) {
+                pkt = row / P.rows_per_pkt;
+                r = row - pkt * P.rows_per_pkt;
+            } else {
+                pkt = P.group_pkt[grp];
+                while (pkt + 1 < P.n_pkts && row >= P.row_start[pkt + 1]) pkt++;
+                r = row - P.row_start[pkt];
+            }
+            k = load_pkt<UNIFORM>(P, pkt);
+            type = r < pre_rows ? 0 : (r - pre_rows <= k.n_sym ? 1 : 2);
+        }
+        const uint32_t s = r - pre_rows;                  // symbol index, 0 = SIGNAL
+
+        // ---- mapper + pilots + carrier map, bins in natural order at buf[g*64 + k]
+        if (type == 1) {
+            const RegimeInfo ri = regime_info((int)k.regime);
+            const uint32_t nb = s == 0 ? 1u : (uint32_t)ri.n_bpsc;       // ftw/ftw_ofdm_mapper.cc:184-191
+            const uint32_t lut_off = s == 0 ? 0u : (uint32_t)ri.lut_off;
+            const uint32_t bit0 = (s == 0 ? 0u : 48u + (s - 1u) * ri.n_cbps) + (uint32_t)(d0 < 0 ? 0 : d0) * nb;
+            // up to 7 carriers x 6 bits + 7 bits of misalignment fit in 64 bits
+            uint64_t raw;
+            __builtin_memcpy(&raw, msg + k.msg_off + (bit0 >> 3), 8);
+            const uint64_t W = __builtin_bswap64(raw) << (bit0 & 7u);    // first wanted bit at bit 63
+            const uint32_t pidx = (k.pilot_base + s) % 127u;             // ftw/ftw_ofdm_pilot_cc.cc:116
+            const float pil = ((T.pilot_neg[pidx >> 5] >> (pidx & 31u)) & 1u) ? -1.f : 1.f;
+            uint32_t used = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                float2 v;
+                if (code[i] >= 0) {
+                    uint32_t idx = (uint32_t)((W << used) >> (64u - nb));
+                    used += nb;
+                    v = s_lut[lut_off + idx];
+                    if (mapped) mapped[((size_t)k.sym_off + s) * 48u + code[i]] = v;
+                } else if (code[i] == -1) {
+                    v = make_float2(0.f, 0.f);
+                } else {
+                    v = make_float2(code[i] == -2 ? pil : -pil, 0.f);
+                }
+                buf[g * 64 + 8 * l + i] = v;
+            }
+        }
+        wave_sync();
+
+        // ---- 64-point inverse DFT as 8 x 8: x[8q+p] = sum_l W8^{lq} W64^{lp} sum_m X[l+8m] W8^{mp}
+        float2 x[8];
+        if (type == 1) {
+#pragma unroll
+            for (int m = 0; m < 8; m++) x[m] = buf[g * 64 + l + 8 * m];
+        }
+        wave_sync();
+        if (type == 1) {
+            idft8(x);
+#pragma unroll
+            for (int p = 1; p < 8; p++) x[p] = cmul(x[p], tw[p]);
+#pragma unroll
+            for (int p = 0; p < 8; p++) buf[g * 64 + 8 * p + l] = x[p];
+        }
+        wave_sync();
+        if (type == 1) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) x[i] = buf[g * 64 + 8 * l + i];   // lane now plays p = l
+        }
+        wave_sync();
+
+        // ---- the row's 80 samples into the staging area (cyclic prefix: out[o] = x[(o+48)%64])
+        if (type == 1) {
+            idft8(x);                                                     // x[q] = sample 8q + l
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                float2 v = make_float2(x[q].x * scale, x[q].y * scale);
+                buf[g * SYM_LEN + 16 + 8 * q + l] = v;
+                if (q >= 6) buf[g * SYM_LEN + 8 * q + l - 48] = v;
+            }
+        } else if (type == 0) {
+#pragma unroll
+            for (int i = 0; i < 10; i++) buf[g * SYM_LEN + l + 8 * i] = s_pre[r * SYM_LEN + l + 8 * i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 10; i++) buf[g * SYM_LEN + l + 8 * i] = make_float2(0.f, 0.f);
+        }
+        wave_sync();
+
+        // ---- 8 rows = 5120 contiguous bytes, 16 B per lane per store
+        float4 *dst = reinterpret_cast<float4 *>(iq + (size_t)grp * 8u * SYM_LEN);
+        const float4 *src = reinterpret_cast<const float4 *>(buf);
+        const uint32_t rows_here = P.total_rows - grp * 8u < 8u ? P.total_rows - grp * 8u : 8u;
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            int e = i * 64 + lane;                        // float4 index, 40 per row
+            float4 v = src[e];
+            if (P.flags & OFDMTX_F_SWAPIQ) v = make_float4(v.y, v.x, v.w, v.z);
+            if ((uint32_t)e < rows_here * 40u) dst[e] = v;
+        }
+        wave_sync();
+    }
+}
+
+}  // namespace
+
+// ======================================================================================
+// Host side
+// ======================================================================================
+
+struct ofdmtx_ctx {
+    int device;
+    uint32_t *d_scr;
+    float2 *d_lut;
+    float2 *d_pre;
+    float2 *d_tw;
+    int n_cu;
+    DevTables tables() const
+    {
+        DevTables t;
+        t.scr_word = d_scr;
+        t.lut = d_lut;
+        t.preamble = d_pre;
+        t.tw64 = d_tw;
+        for (int i = 0; i < 4; i++) t.pilot_neg[i] = OFDMTX_PILOT_NEG[i];
+        return t;
+    }
+};
+
+struct ofdmtx_plan {
+    ofdmtx_ctx *ctx;
+    PlanParams pp;
+    ofdmtx_plan_sizes sizes;
+    // host copies of the layout (ragged); empty for uniform
+    std::vector<PktRec> recs;
+    std::vector<uint32_t> row_start;
+    std::vector<uint32_t> plcp_len, msg_len;
+    PktRec *d_recs;
+    uint32_t *d_row_start;
+    uint32_t *d_group_pkt;
+    ofdmtx_pkt_info uni;   // uniform geometry
+};
+
+extern "C" {
+
+const char *ofdmtx_strerror(int code)
+{
+    switch (code) {
+    case OFDMTX_OK: return "ok";
+    case OFDMTX_EINVAL: return "invalid argument";
+    case OFDMTX_EREGIME: return "regime must be 1..8";
+    case OFDMTX_ELENGTH: return "MPDU-length must be in [0, 3168]";
+    case OFDMTX_EHIP: return "HIP runtime error";
+    case OFDMTX_ENOMEM: return "out of memory";
+    case OFDMTX_ESHAPE: return "block shape not supported (802.11a needs 48 data carriers, 64-point FFT)";
+    case OFDMTX_ETOOBIG: return "batch too large for one launch";
+    default: return "unknown error";
+    }
+}
+
+int ofdmtx_last_hip_error(void) { return g_last_hip; }
+
+uint32_t ofdmtx_crc32(const uint8_t *buf, size_t len)
+{
+    // ftw/ftw_crc32.cc:33-82
+    uint32_t crc = 0xFFFFFFFFu;
+    for (size_t i = 0; i < len; i++) {
+        crc ^= buf[i];
+        for (int j = 0; j < 8; j++) crc = (crc >> 1) ^ (CRC_POLY & (0u - (crc & 1u)));
+    }
+    uint32_t rev = 0;
+    for (int j = 0; j < 32; j++) rev |= ((crc >> j) & 1u) << (31 - j);
+    return rev ^ 0xFFFFFFFFu;
+}
+
+int ofdmtx_packet_info(int regime, int payload_len, double symbol_time, unsigned flags,
+                       ofdmtx_pkt_info *out)
+{
+    if (!out || payload_len < 0) return OFDMTX_EINVAL;
+    if (regime < 1 || regime > 8) return OFDMTX_EREGIME;
+    const RegimeInfo ri = regime_info(regime);
+    const int mpdu = 24 + payload_len;
+    if (mpdu + 4 > MAXLEN) return OFDMTX_ELENGTH;                       // pu:119-121
+    const int nbits = 16 + 32 + 6 + 8 * mpdu;
+    out->n_cbps = ri.n_cbps;
+    out->n_bpsc = ri.n_bpsc;
+    out->n_dbps = ri.n_dbps;
+    out->n_sym = (nbits + ri.n_dbps - 1) / ri.n_dbps;                   // pu:85
+    out->n_data = out->n_sym * ri.n_dbps;                               // pu:94
+    out->n_pad = out->n_data - nbits;                                   // pu:97
+    out->txtime = (int)(5 * symbol_time + symbol_time * out->n_sym) + 2;   // pu:90
+    out->length = mpdu + 4;
+    out->plcp_len = 5 + out->length + (out->n_pad + 6 + 7) / 8;         // pu:160-171,205
+    out->msg_len = 6 + out->n_sym * ri.n_cbps / 8;
+    out->n_rows = ((flags & OFDMTX_F_PREAMBLE) ? PRE_ROWS : 0) + 1 + out->n_sym +
+                  ((flags & OFDMTX_F_ZEROGAP) ? GAP_ROWS : 0);
+    return OFDMTX_OK;
+}
+
+int ofdmtx_create(int device, ofdmtx_ctx **out)
+{
+    if (!out) return OFDMTX_EINVAL;
+    *out = nullptr;
+    HIPCHK(hipSetDevice(device));
+    ofdmtx_ctx *c = new (std::nothrow) ofdmtx_ctx();
+    if (!c) return OFDMTX_ENOMEM;
+    c->device = device;
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    c->n_cu = prop.multiProcessorCount;
+    HIPCHK(hipMalloc(&c->d_scr, 127 * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&c->d_lut, LUT_SIZE * sizeof(float2)));
+    HIPCHK(hipMalloc(&c->d_pre, 320 * sizeof(float2)));
+    HIPCHK(hipMalloc(&c->d_tw, 64 * sizeof(float2)));
+    float lut[2 * LUT_SIZE];
+    lut[0] = -1.f; lut[1] = 0.f; lut[2] = 1.f; lut[3] = 0.f;   // ftw/ftw_ofdm_mapper.cc:179
+    memcpy(lut + 4, OFDMTX_CONST_DEFAULT, sizeof(OFDMTX_CONST_DEFAULT));
+    HIPCHK(hipMemcpy(c->d_scr, OFDMTX_SCR_WORD, sizeof(OFDMTX_SCR_WORD), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->d_lut, lut, sizeof(lut), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->d_pre, OFDMTX_PREAMBLE, sizeof(OFDMTX_PREAMBLE), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->d_tw, OFDMTX_TW64, sizeof(OFDMTX_TW64), hipMemcpyHostToDevice));
+    *out = c;
+    return OFDMTX_OK;
+}
+
+int ofdmtx_destroy(ofdmtx_ctx *c)
+{
+    if (!c) return OFDMTX_EINVAL;
+    hipSetDevice(c->device);
+    hipFree(c->d_scr);
+    hipFree(c->d_lut);
+    hipFree(c->d_pre);
+    hipFree(c->d_tw);
+    delete c;
+    return OFDMTX_OK;
+}
+
+int ofdmtx_set_constellation(ofdmtx_ctx *c, int n_bpsc, const float *re_im, int n)
+{
+    if (!c || !re_im) return OFDMTX_EINVAL;
+    int off;
+    switch (n_bpsc) {
+    case 1: off = 2; break;
+    case 2: off = 4; break;
+    case 4: off = 8; break;
+    case 6: off = 24; break;
+    default: return OFDMTX_EINVAL;
+    }
+    if (n != (1 << n_bpsc)) return OFDMTX_EINVAL;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpy(c->d_lut + off, re_im, (size_t)n * sizeof(float2), hipMemcpyHostToDevice));
+    return OFDMTX_OK;
+}
+
+static inline uint32_t align16(uint32_t v) { return (v + 15u) & ~15u; }
+
+static void plan_common(ofdmtx_plan *pl, ofdmtx_ctx *ctx, uint64_t n, int pilot_mode,
+                        uint32_t pilot_start, unsigned flags, float amp)
+{
+    memset(&pl->pp, 0, sizeof(pl->pp));
+    pl->ctx = ctx;
+    pl->pp.n_pkts = (uint32_t)n;
+    pl->pp.pilot_mode = (uint32_t)pilot_mode;
+    pl->pp.pilot_start = pilot_start % 127u;
+    pl->pp.flags = flags;
+    pl->pp.amp = amp;
+    pl->d_recs = nullptr;
+    pl->d_row_start = nullptr;
+    pl->d_group_pkt = nullptr;
+}
+
+int ofdmtx_plan_uniform(ofdmtx_ctx *ctx, uint64_t n_pkts, int regime, uint32_t payload_len,
+                        uint64_t payload_stride, double symbol_time, int pilot_mode,
+                        uint32_t pilot_start, unsigned flags, float amp, ofdmtx_plan **out)
+{
+    if (!ctx || !out) return OFDMTX_EINVAL;
+    *out = nullptr;
+    if (pilot_mode != OFDMTX_PILOT_REF_STREAM && pilot_mode != OFDMTX_PILOT_PER_PACKET)
+        return OFDMTX_EINVAL;
+    if (payload_len > (uint32_t)MAXLEN) return OFDMTX_ELENGTH;
+    ofdmtx_pkt_info pi;
+    int rc = ofdmtx_packet_info(regime, (int)payload_len, symbol_time, flags, &pi);
+    if (rc) return rc;
+    if (payload_stride == 0) payload_stride = payload_len;
+    if (payload_stride < payload_len) return OFDMTX_EINVAL;
+    if (n_pkts * (uint64_t)pi.n_rows >= 0xFFFFFFF0ull || n_pkts >= 0xFFFFFFF0ull) return OFDMTX_ETOOBIG;
+
+    ofdmtx_plan *pl = new (std::nothrow) ofdmtx_plan();
+    if (!pl) return OFDMTX_ENOMEM;
+    plan_common(pl, ctx, n_pkts, pilot_mode, pilot_start, flags, amp);
+    PlanParams &pp = pl->pp;
+    pp.uniform = 1;
+    pp.regime = (uint32_t)regime;
+    pp.pay_len = payload_len;
+    pp.n_sym = (uint32_t)pi.n_sym;
+    pp.txtime = (uint32_t)pi.txtime & 0xFFFFu;                           // pu:91 masks to 16 bits
+    pp.pay_stride = payload_stride;
+    pp.plcp_stride = align16((uint32_t)pi.plcp_len);
+    pp.msg_stride = align16((uint32_t)pi.msg_len);
+    pp.rows_per_pkt = (uint32_t)pi.n_rows;
+    pp.total_rows = (uint32_t)(n_pkts * (uint64_t)pi.n_rows);
+    pl->uni = pi;
+    ofdmtx_plan_sizes &sz = pl->sizes;
+    sz.n_pkts = n_pkts;
+    sz.payload_bytes = n_pkts ? (n_pkts - 1) * payload_stride + payload_len : 0;
+    sz.plcp_bytes = n_pkts * (uint64_t)pp.plcp_stride + 16;
+    sz.msg_bytes = n_pkts * (uint64_t)pp.msg_stride + 16;
+    sz.n_symbols = n_pkts * (uint64_t)(pi.n_sym + 1);
+    sz.n_rows = pp.total_rows;
+    sz.n_samples = sz.n_rows * SYM_LEN;
+    *out = pl;
+    return OFDMTX_OK;
+}
+
+int ofdmtx_plan_ragged(ofdmtx_ctx *ctx, uint64_t n_pkts, const uint8_t *regimes,
+                       const uint32_t *payload_len, const uint64_t *payload_off,
+                       double symbol_time, int pilot_mode, uint32_t pilot_start, unsigned flags,
+                       float amp, ofdmtx_plan **out)
+{
+    if (!ctx || !out || (n_pkts && (!regimes || !payload_len))) return OFDMTX_EINVAL;
+    *out = nullptr;
+    if (pilot_mode != OFDMTX_PILOT_REF_STREAM && pilot_mode != OFDMTX_PILOT_PER_PACKET)
+        return OFDMTX_EINVAL;
+    if (n_pkts >= 0xFFFFFFF0ull) return OFDMTX_ETOOBIG;
+    ofdmtx_plan *pl = new (std::nothrow) ofdmtx_plan();
+    if (!pl) return OFDMTX_ENOMEM;
+    plan_common(pl, ctx, n_pkts, pilot_mode, pilot_start, flags, amp);
+    PlanParams &pp = pl->pp;
+    pp.uniform = 0;
+    pl->recs.resize(n_pkts);
+    pl->row_start.resize(n_pkts + 1);
+    pl->plcp_len.resize(n_pkts);
+    pl->msg_len.resize(n_pkts);
+    uint64_t pay = 0, plcp = 0, msg = 0, sym = 0, rows = 0, pay_extent = 0;
+    uint64_t pilot = pp.pilot_start;
+    for (uint64_t i = 0; i < n_pkts; i++) {
+        ofdmtx_pkt_info pi;
+        int rc = payload_len[i] > (uint32_t)MAXLEN
+                     ? OFDMTX_ELENGTH
+                     : ofdmtx_packet_info(regimes[i], (int)payload_len[i], symbol_time, flags, &pi);
+        if (rc) {
+            delete pl;
+            return rc;
+        }
+        PktRec &r = pl->recs[i];
+        memset(&r, 0, sizeof(r));
+        r.pay_off = payload_off ? payload_off[i] : pay;
+        r.plcp_off = plcp;
+        r.msg_off = msg;
+        r.sym_off = (uint32_t)sym;
+        r.pay_len = payload_len[i];
+        r.n_sym = (uint32_t)pi.n_sym;
+        r.pilot_base = (uint32_t)(pilot_mode == OFDMTX_PILOT_REF_STREAM ? pilot % 127u : pp.pilot_start);
+        r.txtime = (uint16_t)((uint32_t)pi.txtime & 0xFFFFu);
+        r.regime = regimes[i];
+        pl->row_start[i] = (uint32_t)rows;
+        pl->plcp_len[i] = (uint32_t)pi.plcp_len;
+        pl->msg_len[i] = (uint32_t)pi.msg_len;
+        if (r.pay_off + payload_len[i] > pay_extent) pay_extent = r.pay_off + payload_len[i];
+        pay += payload_len[i];
+        plcp += align16((uint32_t)pi.plcp_len);
+        msg += align16((uint32_t)pi.msg_len);
+        sym += (uint64_t)pi.n_sym + 1;
+        pilot += (uint64_t)pi.n_sym + 1;
+        rows += (uint64_t)pi.n_rows;
+        if (rows >= 0xFFFFFFF0ull || sym >= 0xFFFFFFF0ull) {
+            delete pl;
+            return OFDMTX_ETOOBIG;
+        }
+    }
+    pl->row_start[n_pkts] = (uint32_t)rows;
+    pp.total_rows = (uint32_t)rows;
+    ofdmtx_plan_sizes &sz = pl->sizes;
+    sz.n_pkts = n_pkts;
+    sz.payload_bytes = pay_extent;
+    sz.plcp_bytes = plcp + 16;
+    sz.msg_bytes = msg + 16;
+    sz.n_symbols = sym;
+    sz.n_rows = rows;
+    sz.n_samples = rows * SYM_LEN;
+
+    // packet of the first row of every 8-row group
+    const uint64_t n_groups = (rows + 7) / 8;
+    std::vector<uint32_t> group_pkt(n_groups ? n_groups : 1);
+    uint64_t p = 0;
+    for (uint64_t gidx = 0; gidx < n_groups; gidx++) {
+        const uint64_t row = gidx * 8;
+        while (p + 1 < n_pkts && row >= pl->row_start[p + 1]) p++;
+        group_pkt[gidx] = (uint32_t)p;
+    }
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e == hipSuccess) e = hipMalloc(&pl->d_recs, (n_pkts ? n_pkts : 1) * sizeof(PktRec));
+    if (e == hipSuccess) e = hipMalloc(&pl->d_row_start, (n_pkts + 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&pl->d_group_pkt, group_pkt.size() * sizeof(uint32_t));
+    if (e == hipSuccess && n_pkts)
+        e = hipMemcpy(pl->d_recs, pl->recs.data(), n_pkts * sizeof(PktRec), hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = hipMemcpy(pl->d_row_start, pl->row_start.data(), (n_pkts + 1) * sizeof(uint32_t),
+                      hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = hipMemcpy(pl->d_group_pkt, group_pkt.data(), group_pkt.size() * sizeof(uint32_t),
+                      hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        g_last_hip = (int)e;
+        ofdmtx_plan_destroy(pl);
+        return OFDMTX_EHIP;
+    }
+    pp.recs = pl->d_recs;
+    pp.row_start = pl->d_row_start;
+    pp.group_pkt = pl->d_group_pkt;
+    *out = pl;
+    return OFDMTX_OK;
+}
+
+int ofdmtx_plan_destroy(ofdmtx_plan *pl)
+{
+    if (!pl) return OFDMTX_EINVAL;
+    hipSetDevice(pl->ctx->device);
+    if (pl->d_recs) hipFree(pl->d_recs);
+    if (pl->d_row_start) hipFree(pl->d_row_start);
+    if (pl->d_group_pkt) hipFree(pl->d_group_pkt);
+    delete pl;
+    return OFDMTX_OK;
+}
+
+int ofdmtx_plan_get_sizes(const ofdmtx_plan *pl, ofdmtx_plan_sizes *out)
+{
+    if (!pl || !out) return OFDMTX_EINVAL;
+    *out = pl->sizes;
+    return OFDMTX_OK;
+}
+
+int ofdmtx_plan_get_layout(const ofdmtx_plan *pl, uint64_t *plcp_off, uint64_t *msg_off,
+                           uint64_t *sym_off, uint64_t *sample_off, uint32_t *n_sym,
+                           uint32_t *plcp_len, uint32_t *msg_len, uint32_t *pilot_base)
+{
+    if (!pl) return OFDMTX_EINVAL;
+    const PlanParams &pp = pl->pp;
+    for (uint64_t i = 0; i < pp.n_pkts; i++) {
+        if (pp.uniform) {
+            if (plcp_off) plcp_off[i] = i * pp.plcp_stride;
+            if (msg_off) msg_off[i] = i * pp.msg_stride;
+            if (sym_off) sym_off[i] = i * (pp.n_sym + 1);
+            if (sample_off) sample_off[i] = i * (uint64_t)pp.rows_per_pkt * SYM_LEN;
+            if (n_sym) n_sym[i] = pp.n_sym;
+            if (plcp_len) plcp_len[i] = (uint32_t)pl->uni.plcp_len;
+            if (msg_len) msg_len[i] = (uint32_t)pl->uni.msg_len;
+            if (pilot_base)
+                pilot_base[i] = pp.pilot_mode == OFDMTX_PILOT_REF_STREAM
+                                    ? (uint32_t)((pp.pilot_start + i * (pp.n_sym + 1)) % 127u)
+                                    : pp.pilot_start;
+        } else {
+            const PktRec &r = pl->recs[i];
+            if (plcp_off) plcp_off[i] = r.plcp_off;
+            if (msg_off) msg_off[i] = r.msg_off;
+            if (sym_off) sym_off[i] = r.sym_off;
+            if (sample_off) sample_off[i] = (uint64_t)pl->row_start[i] * SYM_LEN;
+            if (n_sym) n_sym[i] = r.n_sym;
+            if (plcp_len) plcp_len[i] = pl->plcp_len[i];
+            if (msg_len) msg_len[i] = pl->msg_len[i];
+            if (pilot_base) pilot_base[i] = r.pilot_base;
+        }
+    }
+    return OFDMTX_OK;
+}
+
+static int grid_for(const ofdmtx_ctx *c, uint64_t work_items, int items_per_block, int blocks_per_cu)
+{
+    uint64_t need = (work_items + items_per_block - 1) / items_per_block;
+    uint64_t cap = (uint64_t)c->n_cu * blocks_per_cu;
+    uint64_t gsz = need < cap ? need : cap;
+    return (int)(gsz ? gsz : 1);
+}
+
+int ofdmtx_encode_bits(ofdmtx_ctx *ctx, const ofdmtx_plan *pl, const uint8_t *d_payloads,
+                       uint8_t *d_plcp, uint8_t *d_scrambled, uint8_t *d_coded,
+                       uint8_t *d_interleaved, void *stream)
+{
+    if (!ctx || !pl || pl->ctx != ctx || !d_interleaved) return OFDMTX_EINVAL;
+    if (!d_payloads && pl->sizes.payload_bytes) return OFDMTX_EINVAL;
+    if (pl->pp.n_pkts == 0) return OFDMTX_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int grid = grid_for(ctx, pl->pp.n_pkts, ENC_WAVES, 8);
+    hipStream_t st = (hipStream_t)stream;
+    if (pl->pp.uniform)
+        hipLaunchKernelGGL(k_encode_bits<true>, dim3(grid), dim3(64 * ENC_WAVES), 0, st, pl->pp,
+                           ctx->tables(), d_payloads, d_plcp, d_scrambled, d_coded, d_interleaved);
+    else
+        hipLaunchKernelGGL(k_encode_bits<false>, dim3(grid), dim3(64 * ENC_WAVES), 0, st, pl->pp,
+                           ctx->tables(), d_payloads, d_plcp, d_scrambled, d_coded, d_interleaved);
+    HIPCHK(hipGetLastError());
+    return OFDMTX_OK;
+}
+
+int ofdmtx_modulate(ofdmtx_ctx *ctx, const ofdmtx_plan *pl, const uint8_t *d_msg, float *d_mapped,
+                    float *d_iq, void *stream)
+{
+    if (!ctx || !pl || pl->ctx != ctx || !d_msg || !d_iq) return OFDMTX_EINVAL;
+    if (pl->pp.total_rows == 0) return OFDMTX_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint64_t groups = ((uint64_t)pl->pp.total_rows + 7) / 8;
+    const int grid = grid_for(ctx, groups, MOD_WAVES, 8);
+    hipStream_t st = (hipStream_t)stream;
+    if (pl->pp.uniform)
+        hipLaunchKernelGGL(k_modulate<true>, dim3(grid), dim3(64 * MOD_WAVES), 0, st, pl->pp,
+                           ctx->tables(), d_msg, reinterpret_cast<float2 *>(d_mapped),
+                           reinterpret_cast<float2 *>(d_iq));
+    else
+        hipLaunchKernelGGL(k_modulate<false>, dim3(grid), dim3(64 * MOD_WAVES), 0, st, pl->pp,
+                           ctx->tables(), d_msg, reinterpret_cast<float2 *>(d_mapped),
+                           reinterpret_cast<float2 *>(d_iq));
+    HIPCHK(hipGetLastError());
+    return OFDMTX_OK;
+}
+
+int ofdmtx_tx(ofdmtx_ctx *ctx, const ofdmtx_plan *pl, const uint8_t *d_payloads, uint8_t *d_work,
+              float *d_iq, void *stream)
+{
+    if (!d_work) return OFDMTX_EINVAL;
+    int rc = ofdmtx_encode_bits(ctx, pl, d_payloads, nullptr, nullptr, nullptr, d_work, stream);
+    if (rc) return rc;
+    return ofdmtx_modulate(ctx, pl, d_work, nullptr, d_iq, stream);
+}
+
+}  // extern "C"

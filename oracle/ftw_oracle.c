@@ -23,7 +23,7 @@
 #include <string.h>
 
 #define ORC_MAXLEN 3168      /* pu:119 */
-#define ORC_MAX_PLCP 3200    /* 5 + 3168 + tail/pad (<= 27 bytes) */
+#define ORC_MAX_PLCP 3264    /* 5 + 3168 + tail/pad (<= 28 bytes), rounded up */
 #define ORC_MAX_BITS (ORC_MAX_PLCP * 8)
 
 typedef struct {
