@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 802.11a 54 Mbps, 1500-byte packets, payload -> full PPDU IQ.
+
+    python bench.py --gpus N --steps K --warmup W [--packets P]
+
+One "step" is one pass of the transmit chain (bit-level kernel + fused map/IFFT/CP kernel)
+over one batch of P synthetic packets per GPU, payloads already resident in HBM.  With N > 1
+(launched by torch.distributed.run, one rank per GPU) the batch is sharded by packet index:
+every rank processes its own P packets, there is no collective on the data path, and the
+reported value is all ranks' samples divided by the slowest rank's time (weak scaling).
+
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (k_modulate) against
+the HBM peak from its algorithmic bytes and its launch time measured with events on the
+launch stream; `cpu_baseline` times the plain-C oracle port on the host cores (N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from ofdm_amd import _lib  # noqa: E402
+from ofdm_amd.batch import TxContext  # noqa: E402
+
+REGIME = 8            # 54 Mbit/s, 64-QAM r=3/4
+PAYLOAD = 1500
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+
+
+def cpu_baseline(n_sample, threads):
+    """Plain-C oracle port of the same chain on the host (payload -> IQ), packet-parallel."""
+    from oracle import c_oracle
+    info = _lib.packet_info(REGIME, PAYLOAD)
+    rng = np.random.default_rng(2)
+    payloads = rng.integers(0, 256, n_sample * PAYLOAD, dtype=np.uint8)
+    idx = np.arange(n_sample, dtype=np.int64)
+    samples = info.n_rows * 80
+    args = dict(pay_off=idx * PAYLOAD, pay_len=np.full(n_sample, PAYLOAD, np.int32),
+                regimes=np.full(n_sample, REGIME, np.uint8),
+                pilot_off=((idx * (info.n_sym + 1)) % 127).astype(np.int32),
+                msg_off=idx * info.msg_len, iq_off=idx * samples,
+                msg_total=n_sample * info.msg_len, iq_total=n_sample * samples,
+                amp=0.3, flags=3, threads=threads, want_msg=False, want_iq=True)
+    c_oracle.tx_batch(payloads[:PAYLOAD * 64], args["pay_off"][:64], args["pay_len"][:64], args["regimes"][:64],
+                      args["pilot_off"][:64], args["msg_off"][:64], args["iq_off"][:64],
+                      64 * info.msg_len, 64 * samples, threads=1, want_msg=False)   # warm caches / page in
+    t0 = time.perf_counter()
+    c_oracle.tx_batch(payloads, **args)
+    dt = time.perf_counter() - t0
+    return {"value": n_sample * samples / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
+            "sample": "%d packets (54 Mbps, 1500 B) payload->IQ by oracle/ftw_oracle.c, %.1f s wall on %d threads; "
+                      "restatement, not GNU Radio" % (n_sample, dt, threads)}
+
+
+def load_traffic(workload_key):
+    """HBM bytes per k_modulate launch from the committed PMC passes (profiles/), or None."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        return t.get(workload_key)
+    except (OSError, ValueError):
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--packets", type=int, default=1_000_000, help="packets per GPU per step")
+    ap.add_argument("--cpu-sample", type=int, default=40_000, help="packets timed on the CPU baseline (0 = skip)")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    ctx = TxContext(local)
+    n = a.packets
+    info = _lib.packet_info(REGIME, PAYLOAD)
+    # packets are sharded by index: rank r holds packets [r*n, (r+1)*n); the stream-wide pilot
+    # counter of the reference continues across shards
+    pilot_start = (rank * n * (info.n_sym + 1)) % 127
+    plan = ctx.plan_uniform(n, REGIME, PAYLOAD, pilot_start=pilot_start)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(2 + rank)
+    payloads = torch.randint(0, 256, (n * PAYLOAD,), dtype=torch.uint8, device=dev, generator=gen)
+    msg = plan.alloc_msg()
+    iq = plan.alloc_iq()
+
+    def step(events=None):
+        if events is not None:
+            events[0].record()
+        plan.encode_bits(payloads, out=msg)
+        if events is not None:
+            events[1].record()
+        plan.modulate(msg, out=iq)
+        if events is not None:
+            events[2].record()
+
+    for _ in range(a.warmup):
+        step()
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(a.steps)]
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(evs[i])          # events ride on the stream the kernels are launched on
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    enc_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
+    mod_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))
+
+    if rank == 0:
+        samples_per_step = world * plan.n_samples
+        value = samples_per_step * a.steps / dt / 1e6
+        alg_bytes = n * (info.msg_len + info.n_rows * 640)     # mapper message read + IQ rows written
+        achieved = alg_bytes / (mod_ms * 1e-3) / 1e9
+        workload_key = "mod_54M_1500B_%dpk" % n
+        out = {
+            "metric": "baseband IQ Msamples/s (node), 802.11a 54Mbps 1500B packets",
+            "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "802.11a 54 Mbps (64-QAM r3/4), %d x 1500-byte packets per GPU, payload -> "
+                                   "full PPDU IQ (4 preamble rows + SIGNAL + %d DATA symbols + 13 zero rows)"
+                                   % (n, info.n_sym),
+                       "packets_per_gpu": n, "samples_per_packet": info.n_rows * 80,
+                       "parallelism": "packets sharded by index over %d GPU(s), no collective" % world},
+            "kernel_ms": {"k_encode_bits": enc_ms, "k_modulate": mod_ms},
+            "roofline": {"bound": "hbm", "kernel": "k_modulate", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(workload_key),
+                         "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if world == 1 and a.cpu_sample > 0:
+            threads = min(16, os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(a.cpu_sample, threads)
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
