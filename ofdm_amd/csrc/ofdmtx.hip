@@ -100,6 +100,8 @@ struct DevTables {
     const float2 *lut;          // LUT_SIZE
     const float2 *preamble;     // 320
     const float2 *tw64;         // 64
+    const uint32_t *crc_tab;    // 4 x 256, slicing-by-4 tables of the reflected CRC-32
+    const uint32_t *xpow8;      // x^(8n) mod P for n = 0..MAXLEN, reflected representation
     uint32_t pilot_neg[4];
 };
 
@@ -152,11 +154,20 @@ __device__ inline void wave_sync()
 // ======================================================================================
 // Bit-level kernel
 // ======================================================================================
-
-// MAC header of pu:28-36 (duration bytes 2,3 filled per packet, pu:91)
-__device__ const uint8_t MAC_HDR[24] = {0x08, 0x00, 0x00, 0x00, 0x00, 0x60, 0x08, 0xcd,
-                                        0x37, 0xa6, 0x00, 0x20, 0xd6, 0x01, 0x3c, 0xf1,
-                                        0x00, 0x60, 0x08, 0xad, 0x3b, 0xaf, 0x00, 0x00};
+//
+// One wavefront builds one packet.  The bit stream is kept as MSB-first 32-bit words
+// (stream bit t of a word at bit 31-t) so that scrambling, encoding and puncturing are word
+// operations:
+//   1. natural-order MPDU (MAC header + payload) as dwords in LDS
+//   2. CRC-32: every lane folds a chunk of dwords (slicing-by-4), multiplies its remainder
+//      by x^(8*bytes behind the chunk) mod P, and the lanes' results are XOR-reduced
+//   3. PLCP stream words = bit-reversed MPDU dwords + SIGNAL + FCS, XOR scrambler words,
+//      tail bits cleared  -> U[] in LDS
+//   4. SIGNAL symbol: 48 coded bits, one lane each
+//   5. DATA symbols: one lane per OFDM symbol; the symbol's N_dbps(+6) scrambled bits are
+//      pulled into registers, encoded + punctured piecewise with shift/XOR and bit-spread
+//      tricks, and interleaved with compile-time bit moves -> LDS
+//   6. the message is copied out with coalesced dword stores.
 
 constexpr uint32_t CRC_POLY = 0xEDB88320u;   // ftw/ftw_crc32.cc:45
 
@@ -164,9 +175,9 @@ constexpr uint32_t CRC_POLY = 0xEDB88320u;   // ftw/ftw_crc32.cc:45
 __device__ inline uint32_t crc_mulmod(uint32_t a, uint32_t b)
 {
     uint32_t p = 0;
-#pragma unroll 1
+#pragma unroll 4
     for (int i = 0; i < 32; i++) {
-        p ^= b & (0u - ((a >> 31) & 1u));
+        p ^= b & (0u - (a >> 31));
         a <<= 1;
         b = (b >> 1) ^ (CRC_POLY & (0u - (b & 1u)));
     }
@@ -185,61 +196,147 @@ __device__ inline uint32_t coded_bit(const uint32_t *U, uint32_t P)
     return __popc(win & ((P & 1u) ? 0x4Fu : 0x6Du)) & 1u;
 }
 
-// Index into the coded DATA stream of punctured index q: pu:309-341
-template <int PUNCT>
-__device__ inline uint32_t unpuncture(uint32_t q)
+// bits [off, off+len) of an MSB-first word array, right-aligned (off/len constant after unrolling)
+template <int NX>
+__device__ inline uint32_t getbits(const uint32_t (&X)[NX], int off, int len)
 {
-    if (PUNCT == 1) {
-        uint32_t r = q & 3u;
-        return 6u * (q >> 2) + (r == 3u ? 5u : r);
+    const int w = off >> 5, o = off & 31;
+    const uint32_t mask = (1u << len) - 1u;
+    if (o + len <= 32) return (X[w] >> (32 - o - len)) & mask;
+    return ((X[w] << (o + len - 32)) | (X[w + 1] >> (64 - o - len))) & mask;
+}
+
+template <int NW>
+__device__ inline void putbits(uint32_t (&W)[NW], int off, int len, uint32_t v)
+{
+    const int w = off >> 5, o = off & 31;
+    if (o + len <= 32) {
+        W[w] |= v << (32 - o - len);
+    } else {
+        W[w] |= v >> (o + len - 32);
+        W[w + 1] |= v << (64 - o - len);
     }
-    if (PUNCT == 2) return 4u * (q / 3u) + q % 3u;
-    return q;
 }
 
-// Source position k (before interleaving) of interleaved position j within a symbol of N
-// coded bits: inverse of pu:241-253 followed by pu:267-273.
-template <int NBPSC>
-__device__ inline uint32_t deinterleave_pos(uint32_t j)
+__device__ inline uint32_t spread8(uint32_t x)      // bit k -> bit 2k, 8 bits
 {
-    constexpr uint32_t R = 3u * NBPSC;                 // N_cbps / 16
-    constexpr uint32_t S = NBPSC / 2 > 1 ? NBPSC / 2 : 1;
-    uint32_t c = j / R, u = j % R;
-    uint32_t r = S * (u / S) + ((u % S) + c) % S;
-    return 16u * r + c;
+    x = (x | (x << 4)) & 0x0F0Fu;
+    x = (x | (x << 2)) & 0x3333u;
+    x = (x | (x << 1)) & 0x5555u;
+    return x;
+}
+__device__ inline uint32_t spread16(uint32_t x)     // bit k -> bit 2k, 16 bits
+{
+    x = (x | (x << 8)) & 0x00FF00FFu;
+    x = (x | (x << 4)) & 0x0F0F0F0Fu;
+    x = (x | (x << 2)) & 0x33333333u;
+    x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
+__device__ inline uint32_t spread3to4(uint32_t x)   // 4 groups of 3 bits -> top 3 bits of 4 nibbles
+{
+    return ((x & 0xE00u) << 4) | ((x & 0x1C0u) << 3) | ((x & 0x038u) << 2) | ((x & 0x007u) << 1);
+}
+__device__ inline uint32_t compress3of4(uint32_t x) // keep the top 3 bits of each of 8 nibbles -> 24 bits
+{
+    uint32_t t = (x >> 1) & 0x77777777u;
+    t = (t & 0x07070707u) | ((t & 0x70707070u) >> 1);
+    t = (t & 0x003F003Fu) | ((t & 0x3F003F00u) >> 2);
+    return (t & 0x00000FFFu) | ((t & 0x0FFF0000u) >> 4);
 }
 
+// Encoder + puncturing of one piece.  V holds INB+6 consecutive scrambled bits, oldest first
+// (the first six are the encoder's history); returns OUTB punctured coded bits, first bit in
+// the MSB of the field.  Generators pu:287-307; puncturing patterns pu:316-341:
+//   rate 1/2: A0 B0 A1 B1 ...          8 in -> 16 out
+//   rate 3/4: A0 B0 A1 B2 per 3 in    12 in -> 16 out   (coded index mod 6 in {0,1,2,5})
+//   rate 2/3: A0 B0 A1 per 2 in       16 in -> 24 out   (coded index mod 4 in {0,1,2})
+template <int PUNCT> struct Piece;
+template <> struct Piece<0> { static constexpr int INB = 8, OUTB = 16; };
+template <> struct Piece<1> { static constexpr int INB = 12, OUTB = 16; };
+template <> struct Piece<2> { static constexpr int INB = 16, OUTB = 24; };
+
+template <int PUNCT>
+__device__ inline uint32_t encode_piece(uint32_t V)
+{
+    constexpr uint32_t mask = (1u << Piece<PUNCT>::INB) - 1u;
+    const uint32_t A = (V ^ (V >> 2) ^ (V >> 3) ^ (V >> 5) ^ (V >> 6)) & mask;   // 133 octal
+    const uint32_t B = (V ^ (V >> 1) ^ (V >> 2) ^ (V >> 3) ^ (V >> 6)) & mask;   // 171 octal
+    if (PUNCT == 0) return (spread8(A) << 1) | spread8(B);
+    if (PUNCT == 1) {
+        const uint32_t Ae = spread3to4(A), Be = spread3to4(B);
+        return (Ae & 0x8888u) | (((Be & 0xAAAAu) | (Ae & 0x4444u)) >> 1);
+    }
+    return compress3of4((spread16(A) << 1) | spread16(B));
+}
+
+// DATA symbols of one packet, one lane per symbol.  OUTW: MSB-first words, word 2 holds the
+// first 32 interleaved DATA bits (words 0,1 carry the SIGNAL symbol).
 template <int NBPSC, int PUNCT>
-__device__ inline void emit_message_bits(const uint32_t *U, uint32_t n_sym, uint8_t *cod_out,
-                                         uint8_t *itl_out, int lane)
+__device__ inline void encode_data_symbols(const uint32_t *U, uint32_t *OUTW, uint32_t n_sym,
+                                           uint8_t *cod_out, int lane)
 {
-    constexpr uint32_t N = 48u * NBPSC;
-    const uint32_t msg_bits = 48u + n_sym * N;
-    const uint32_t my = 8u * (lane >> 3) + 7u - (lane & 7u);   // ballot bit `lane` = stream bit `my`
-    for (uint32_t j0 = 0; j0 < msg_bits; j0 += 64) {
-        uint32_t j = j0 + my;
-        uint32_t bi = 0, bc = 0;
-        if (j < msg_bits) {
-            if (j < 48u) {
-                bc = coded_bit(U, j);
-                bi = coded_bit(U, deinterleave_pos<1>(j));      // SIGNAL: N = 48, first permutation only
-            } else {
-                uint32_t jj = j - 48u;
-                uint32_t s = jj / N, pos = jj % N;
-                bc = cod_out ? coded_bit(U, 48u + unpuncture<PUNCT>(jj)) : 0u;
-                bi = coded_bit(U, 48u + unpuncture<PUNCT>(s * N + deinterleave_pos<NBPSC>(pos)));
-            }
-        }
-        unsigned long long mi = __ballot(bi);
-        if (lane == 0) *reinterpret_cast<unsigned long long *>(itl_out + (j0 >> 3)) = mi;
+    constexpr int N = 48 * NBPSC;                                  // coded bits per symbol
+    constexpr int NDBPS = PUNCT == 0 ? N / 2 : (PUNCT == 1 ? N * 3 / 4 : N * 2 / 3);
+    constexpr int R = 3 * NBPSC;                                   // N / 16
+    constexpr int S = NBPSC / 2 > 1 ? NBPSC / 2 : 1;
+    constexpr int NW = (N + 31) / 32;
+    constexpr int NX = (NDBPS + 6 + 31) / 32 + 1;
+    constexpr int INB = Piece<PUNCT>::INB, OUTB = Piece<PUNCT>::OUTB;
+    static_assert(NDBPS % INB == 0, "symbol is a whole number of pieces");
+
+    for (uint32_t s = lane; s < n_sym; s += 64) {
+        // scrambled bits [24 + s*NDBPS - 6, 24 + (s+1)*NDBPS), left-aligned in X
+        const uint32_t b0 = 18u + s * NDBPS;
+        const uint32_t w0 = b0 >> 5, o = b0 & 31u;
+        uint32_t X[NX];
+#pragma unroll
+        for (int i = 0; i < NX - 1; i++) X[i] = __funnelshift_l(U[w0 + i + 1], U[w0 + i], o);
+        X[NX - 1] = 0;
+
+        uint32_t Pw[NW + 1];                                       // punctured coded bits of the symbol
+#pragma unroll
+        for (int i = 0; i <= NW; i++) Pw[i] = 0;
+#pragma unroll
+        for (int p = 0; p < NDBPS / INB; p++)
+            putbits(Pw, p * OUTB, OUTB, encode_piece<PUNCT>(getbits(X, p * INB, INB + 6)));
+
         if (cod_out) {
-            unsigned long long mc = __ballot(bc);
-            if (lane == 0) *reinterpret_cast<unsigned long long *>(cod_out + (j0 >> 3)) = mc;
+#pragma unroll
+            for (int t = 0; t < N / 8; t++)
+                cod_out[6u + s * (N / 8) + t] = (uint8_t)(Pw[t >> 2] >> (24 - 8 * (t & 3)));
+        }
+
+        // interleaver: bit k = 16r + c of the symbol goes to j = R*c + S*(u/S) + ((r - c) mod S),
+        // u = r (pu:241-253 then pu:267-273); written here as a gather over j
+        uint32_t out[NW];
+#pragma unroll
+        for (int i = 0; i < NW; i++) out[i] = 0;
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            const int c = j / R, u = j % R;
+            const int r = S * (u / S) + ((u % S) + c) % S;
+            const int k = 16 * r + c;
+            out[j >> 5] |= ((Pw[k >> 5] >> (31 - (k & 31))) & 1u) << (31 - (j & 31));
+        }
+
+        if (N % 32 == 0) {
+#pragma unroll
+            for (int i = 0; i < NW; i++) OUTW[2u + s * (N / 32) + i] = out[i];
+        } else {
+            // N = 48: three halfwords; halfword h (stream order) lives at u16 index h^1
+            uint16_t *H = reinterpret_cast<uint16_t *>(OUTW + 2);
+            const uint32_t h0 = 3u * s;
+            H[(h0 + 0) ^ 1u] = (uint16_t)(out[0] >> 16);
+            H[(h0 + 1) ^ 1u] = (uint16_t)out[0];
+            H[(h0 + 2) ^ 1u] = (uint16_t)(out[1] >> 16);
         }
     }
 }
 
 constexpr int ENC_WAVES = 4;
+constexpr int ENC_A_WORDS = 1600;   // natural MPDU (2 zero words + <= 792 words), later the message words
+constexpr int ENC_U_WORDS = MAX_PLCP / 4 + 4;
 
 template <bool UNIFORM>
 __global__ void __launch_bounds__(64 * ENC_WAVES)
@@ -247,15 +344,17 @@ k_encode_bits(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads,
               uint8_t *__restrict__ plcp_out, uint8_t *__restrict__ scr_out,
               uint8_t *__restrict__ cod_out, uint8_t *__restrict__ itl_out)
 {
-    __shared__ __align__(16) uint8_t s_img[ENC_WAVES][MAX_PLCP + 16];
-    __shared__ __align__(16) uint32_t s_u[ENC_WAVES][MAX_PLCP / 4 + 4];
+    __shared__ __align__(16) uint32_t s_a[ENC_WAVES][ENC_A_WORDS];
+    __shared__ __align__(16) uint32_t s_u[ENC_WAVES][ENC_U_WORDS];
+    __shared__ uint32_t s_crc[1024];
     __shared__ uint32_t s_scr[127];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < 127; i += 64 * ENC_WAVES) s_scr[i] = T.scr_word[i];
+    for (int i = tid; i < 1024; i += 64 * ENC_WAVES) s_crc[i] = T.crc_tab[i];
     __syncthreads();
 
-    uint8_t *img = s_img[wave];
+    uint32_t *A = s_a[wave];
     uint32_t *U = s_u[wave];
 
     for (uint32_t p = blockIdx.x * ENC_WAVES + wave; p < P.n_pkts; p += gridDim.x * ENC_WAVES) {
@@ -265,96 +364,136 @@ k_encode_bits(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads,
         const uint32_t length = mpdu_len + 4u;                                   // pu:193
         const uint32_t n_pad = k.n_sym * ri.n_dbps - (54u + 8u * mpdu_len);      // pu:97
         const uint32_t plcp_len = 5u + length + (n_pad + 13u) / 8u;              // pu:160-171
-        const uint32_t n_words = (plcp_len + 3u) / 4u;
+        const uint32_t n_words = (plcp_len + 3u) / 4u;                           // stream words
+        const uint32_t n_dw = (mpdu_len + 3u) / 4u;                              // MPDU dwords
+        const uint32_t msg_len = 6u + k.n_sym * ri.n_cbps / 8u;
 
-        // ---- MPDU in natural byte order at img[5..] (pu:100)
-        for (uint32_t i = lane; i < mpdu_len; i += 64) {
-            uint8_t b;
-            if (i < 24u) {
-                b = MAC_HDR[i];
-                if (i == 2u) b = (uint8_t)(k.txtime >> 8);
-                if (i == 3u) b = (uint8_t)k.txtime;
-            } else {
-                b = payloads[k.pay_off + (i - 24u)];
+        // ---- 1. MPDU in natural byte order (pu:28-36,100), Dw[-2], Dw[-1] and the tail zero
+        uint32_t *Dw = A + 2;
+        {
+            const uintptr_t ad = reinterpret_cast<uintptr_t>(payloads + k.pay_off);
+            const uint32_t a = (uint32_t)(ad & 3u);
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(ad - a);
+            for (uint32_t i = lane; i < n_words + 3u; i += 64) {
+                const int idx = (int)i - 2;
+                uint32_t v = 0;
+                if (idx >= 6 && (uint32_t)idx < n_dw) {
+                    const uint32_t j = (uint32_t)idx - 6u;
+                    const uint32_t nb = k.pay_len - 4u * j < 4u ? k.pay_len - 4u * j : 4u;
+                    const uint32_t lo = q[j];
+                    const uint32_t hi = (a + nb > 4u) ? q[j + 1] : 0u;
+                    v = (uint32_t)((((uint64_t)hi << 32) | lo) >> (8u * a));
+                    if (nb < 4u) v &= (1u << (8u * nb)) - 1u;
+                } else if (idx >= 0 && idx < 6) {
+                    switch (idx) {
+                    case 0: v = 0x00000008u | ((k.txtime >> 8) & 0xFFu) << 16 | (k.txtime & 0xFFu) << 24; break;  // pu:91
+                    case 1: v = 0xcd086000u; break;
+                    case 2: v = 0x2000a637u; break;
+                    case 3: v = 0xf13c01d6u; break;
+                    case 4: v = 0xad086000u; break;
+                    default: v = 0x0000af3bu; break;
+                    }
+                }
+                A[i] = v;
             }
-            img[5u + i] = b;
         }
         wave_sync();
 
-        // ---- CRC-32 over the natural-order MPDU (ftw/ftw_crc32.cc:52-57): every lane takes a
-        // right-aligned chunk of c bytes, chunks are merged with multiplications by x^(8c*2^s).
-        const uint32_t c = (mpdu_len + 63u) / 64u;
-        const int start = (int)mpdu_len - (64 - lane) * (int)c;
-        uint32_t st = (start <= 0 && start + (int)c > 0) ? 0xFFFFFFFFu : 0u;
-        for (int j = start < 0 ? 0 : start; j < start + (int)c; j++) {
-            st ^= img[5 + j];
+        // ---- 2. CRC-32 of the MPDU (ftw/ftw_crc32.cc:52-57)
+        uint32_t fcs;
+        {
+            const uint32_t c4 = (n_dw + 63u) / 64u;
+            const uint32_t j0 = lane * c4;
+            uint32_t st = lane == 0 ? 0xFFFFFFFFu : 0u;
+            for (uint32_t j = j0; j < j0 + c4; j++) {
+                if (4u * j + 4u <= mpdu_len) {
+                    st ^= Dw[j];
+                    st = s_crc[768 + (st & 0xFFu)] ^ s_crc[512 + ((st >> 8) & 0xFFu)] ^
+                         s_crc[256 + ((st >> 16) & 0xFFu)] ^ s_crc[st >> 24];
+                } else if (4u * j < mpdu_len) {
+                    const uint32_t d = Dw[j];
+                    for (uint32_t b = 0; b < mpdu_len - 4u * j; b++)
+                        st = (st >> 8) ^ s_crc[(st ^ (d >> (8u * b))) & 0xFFu];
+                }
+            }
+            const uint32_t endb = 4u * (j0 + c4) < mpdu_len ? 4u * (j0 + c4) : mpdu_len;
+            uint32_t part = crc_mulmod(st, T.xpow8[mpdu_len - endb]);
 #pragma unroll
-            for (int b = 0; b < 8; b++) st = (st >> 1) ^ (CRC_POLY & (0u - (st & 1u)));
+            for (int off = 32; off >= 1; off >>= 1) part ^= __shfl_xor(part, off);
+            fcs = __brev(part) ^ 0xFFFFFFFFu;      // state bit-reversed, then ^~0 (ftw/ftw_crc32.cc:58-63,75)
         }
-        uint32_t mul = 0x80000000u;                       // x^0
-        for (uint32_t i = 0; i < 8u * c; i++) mul = (mul >> 1) ^ (CRC_POLY & (0u - (mul & 1u)));
-#pragma unroll 1
-        for (int s = 0; s < 6; s++) {
-            uint32_t left = __shfl(st, lane - (1 << s));
-            uint32_t merged = crc_mulmod(mul, left) ^ st;
-            if ((lane & ((2 << s) - 1)) == ((2 << s) - 1)) st = merged;
-            mul = crc_mulmod(mul, mul);
-        }
-        // final state bit-reversed, then ^0xFFFFFFFF (ftw/ftw_crc32.cc:58-63,75)
-        const uint32_t fcs = __brev(__shfl(st, 63)) ^ 0xFFFFFFFFu;
 
-        // ---- PLCP image: SIGNAL, SERVICE, bit-reversed MPDU, FCS, tail/pad (pu:128-205)
-        for (uint32_t i = lane; i < mpdu_len; i += 64)
-            img[5u + i] = (uint8_t)(__brev((uint32_t)img[5u + i]) >> 24);       // pu:208-218
-        if (lane == 0) {
-            uint32_t rev = __brev(length) >> 20;                                 // pu:147-150
-            uint32_t par = (__popc(rev & 0xFFFu) + __popc((uint32_t)ri.rate_bits)) & 1u;   // pu:153-157
-            uint32_t field = ((uint32_t)ri.rate_bits << 20) | ((rev & 0xFFFu) << 7) | (par << 6);
-            img[0] = (uint8_t)(field >> 16);
-            img[1] = (uint8_t)(field >> 8);
-            img[2] = (uint8_t)field;
-            img[3] = 0;
-            img[4] = 0;                                                          // SERVICE pu:183
-            img[5u + mpdu_len + 0] = (uint8_t)(fcs >> 24);                       // pu:372 ">I"
-            img[5u + mpdu_len + 1] = (uint8_t)(fcs >> 16);
-            img[5u + mpdu_len + 2] = (uint8_t)(fcs >> 8);
-            img[5u + mpdu_len + 3] = (uint8_t)fcs;
-        }
-        for (uint32_t i = 5u + length + lane; i < 4u * n_words + 4u; i += 64) img[i] = 0;
-        wave_sync();
-
-        if (plcp_out)
-            for (uint32_t i = lane; i < plcp_len; i += 64) plcp_out[k.plcp_off + i] = img[i];
-
-        // ---- scrambler on MSB-first words (pu:344-367)
-        const uint32_t tz = 40u + 8u * length;            // first tail bit
-        for (uint32_t w = lane; w <= n_words; w += 64) {
-            uint32_t v = __builtin_bswap32(reinterpret_cast<const uint32_t *>(img)[w]);
-            if (w == 0)
-                v ^= s_scr[0] >> 24;                      // bits 24..31 are SERVICE bits 0..7
-            else
-                v ^= s_scr[(32u * w - 24u) % 127u];
-            if (w == (tz >> 5)) v &= ~(0x3Fu << (26u - (tz & 31u)));   // six tail bits to 0, pu:361-362
-            U[w] = v;
+        // ---- 3. PLCP stream words (pu:128-205) and scrambler (pu:344-367)
+        {
+            const uint32_t rev = __brev(length) >> 20;                           // pu:147-150
+            const uint32_t par = (__popc(rev & 0xFFFu) + __popc((uint32_t)ri.rate_bits)) & 1u;   // pu:153-157
+            const uint32_t field = ((uint32_t)ri.rate_bits << 20) | ((rev & 0xFFFu) << 7) | (par << 6);
+            const uint32_t F = 5u + mpdu_len, wf = F >> 2, fsh = 8u * (F & 3u);
+            const uint32_t tz = 40u + 8u * length;                               // first tail bit
+            for (uint32_t w = lane; w <= n_words; w += 64) {
+                // MPDU bytes 4w-5 .. 4w-2, bit order reversed inside every byte (pu:208-218)
+                uint32_t v = __brev((Dw[(int)w - 2] >> 24) | (Dw[(int)w - 1] << 8));
+                if (w == 0) v |= field << 8;                                     // SIGNAL; SERVICE = 0 (pu:183)
+                if (w == wf) v |= fcs >> fsh;                                    // FCS big-endian (pu:372)
+                if (w == wf + 1u && fsh) v |= fcs << (32u - fsh);
+                if (plcp_out && 4u * w < plcp_len)
+                    *reinterpret_cast<uint32_t *>(plcp_out + k.plcp_off + 4u * w) = __builtin_bswap32(v);
+                if (w == 0)
+                    v ^= s_scr[0] >> 24;                  // bits 24..31 are SERVICE bits 0..7
+                else
+                    v ^= s_scr[(32u * w - 24u) % 127u];
+                if (w == (tz >> 5)) v &= ~(0x3Fu << (26u - (tz & 31u)));         // six tail bits to 0, pu:361-362
+                U[w] = v;
+                if (scr_out && 4u * w < plcp_len)
+                    *reinterpret_cast<uint32_t *>(scr_out + k.plcp_off + 4u * w) = __builtin_bswap32(v);
+            }
         }
         wave_sync();
 
-        if (scr_out)
-            for (uint32_t i = lane; i < plcp_len; i += 64)
-                scr_out[k.plcp_off + i] = (uint8_t)(U[i >> 2] >> (24u - 8u * (i & 3u)));
-
-        // ---- encoder + puncture + interleaver, 64 message bits per step
+        // ---- 4. SIGNAL symbol: 48 coded bits, N = 48 first permutation only (pu:245-249)
+        uint32_t *OUTW = A;
         uint8_t *co = cod_out ? cod_out + k.msg_off : nullptr;
-        uint8_t *io = itl_out + k.msg_off;
+        {
+            const uint32_t t = 63u - lane;                // ballot bit `lane` = stream bit 63 - lane
+            uint32_t bi = 0, bc = 0;
+            if (t < 48u) {
+                bi = coded_bit(U, 16u * (t % 3u) + t / 3u);
+                bc = coded_bit(U, t);
+            }
+            const unsigned long long mi = __ballot(bi);
+            const unsigned long long mc = __ballot(bc);
+            const uint32_t ndw = (k.n_sym * ri.n_cbps) >> 5;      // whole DATA words
+            if (lane == 0) {
+                OUTW[0] = (uint32_t)(mi >> 48);
+                OUTW[1] = (uint32_t)(mi >> 16);
+                OUTW[2u + ndw] = 0;                       // partly filled / trailing words
+                OUTW[3u + ndw] = 0;
+                if (co) {
+#pragma unroll
+                    for (int b = 0; b < 6; b++) co[b] = (uint8_t)(mc >> (56 - 8 * b));
+                }
+            }
+        }
+
+        // ---- 5. DATA symbols
         switch (k.regime) {
-        case 1: emit_message_bits<1, 0>(U, k.n_sym, co, io, lane); break;
-        case 2: emit_message_bits<1, 1>(U, k.n_sym, co, io, lane); break;
-        case 3: emit_message_bits<2, 0>(U, k.n_sym, co, io, lane); break;
-        case 4: emit_message_bits<2, 1>(U, k.n_sym, co, io, lane); break;
-        case 5: emit_message_bits<4, 0>(U, k.n_sym, co, io, lane); break;
-        case 6: emit_message_bits<4, 1>(U, k.n_sym, co, io, lane); break;
-        case 7: emit_message_bits<6, 2>(U, k.n_sym, co, io, lane); break;
-        default: emit_message_bits<6, 1>(U, k.n_sym, co, io, lane); break;
+        case 1: encode_data_symbols<1, 0>(U, OUTW, k.n_sym, co, lane); break;
+        case 2: encode_data_symbols<1, 1>(U, OUTW, k.n_sym, co, lane); break;
+        case 3: encode_data_symbols<2, 0>(U, OUTW, k.n_sym, co, lane); break;
+        case 4: encode_data_symbols<2, 1>(U, OUTW, k.n_sym, co, lane); break;
+        case 5: encode_data_symbols<4, 0>(U, OUTW, k.n_sym, co, lane); break;
+        case 6: encode_data_symbols<4, 1>(U, OUTW, k.n_sym, co, lane); break;
+        case 7: encode_data_symbols<6, 2>(U, OUTW, k.n_sym, co, lane); break;
+        default: encode_data_symbols<6, 1>(U, OUTW, k.n_sym, co, lane); break;
+        }
+        wave_sync();
+
+        // ---- 6. message bytes = OUTW stream shifted by 16 bits (6 SIGNAL bytes lead)
+        {
+            uint32_t *dst = reinterpret_cast<uint32_t *>(itl_out + k.msg_off);
+            const uint32_t n_mw = (msg_len + 3u) / 4u;
+            for (uint32_t q = lane; q < n_mw; q += 64)
+                dst[q] = __builtin_bswap32((OUTW[q] << 16) | (OUTW[q + 1] >> 16));
         }
         wave_sync();
     }
@@ -566,6 +705,8 @@ struct ofdmtx_ctx {
     float2 *d_lut;
     float2 *d_pre;
     float2 *d_tw;
+    uint32_t *d_crc;
+    uint32_t *d_xpow8;
     int n_cu;
     DevTables tables() const
     {
@@ -574,6 +715,8 @@ struct ofdmtx_ctx {
         t.lut = d_lut;
         t.preamble = d_pre;
         t.tw64 = d_tw;
+        t.crc_tab = d_crc;
+        t.xpow8 = d_xpow8;
         for (int i = 0; i < 4; i++) t.pilot_neg[i] = OFDMTX_PILOT_NEG[i];
         return t;
     }
@@ -671,6 +814,27 @@ int ofdmtx_create(int device, ofdmtx_ctx **out)
     HIPCHK(hipMemcpy(c->d_lut, lut, sizeof(lut), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->d_pre, OFDMTX_PREAMBLE, sizeof(OFDMTX_PREAMBLE), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->d_tw, OFDMTX_TW64, sizeof(OFDMTX_TW64), hipMemcpyHostToDevice));
+    {
+        // CRC helper tables: slicing-by-4 and the powers x^(8n) mod P used to merge lane chunks
+        std::vector<uint32_t> tab(1024), xp(MAXLEN + 1);
+        for (uint32_t b = 0; b < 256; b++) {
+            uint32_t crc = b;
+            for (int j = 0; j < 8; j++) crc = (crc >> 1) ^ (CRC_POLY & (0u - (crc & 1u)));   // ftw/ftw_crc32.cc:41-48
+            tab[b] = crc;
+        }
+        for (int t = 1; t < 4; t++)
+            for (uint32_t b = 0; b < 256; b++)
+                tab[256 * t + b] = (tab[256 * (t - 1) + b] >> 8) ^ tab[tab[256 * (t - 1) + b] & 0xFFu];
+        uint32_t v = 0x80000000u;
+        for (int n = 0; n <= MAXLEN; n++) {
+            xp[n] = v;
+            for (int j = 0; j < 8; j++) v = (v >> 1) ^ (CRC_POLY & (0u - (v & 1u)));
+        }
+        HIPCHK(hipMalloc(&c->d_crc, tab.size() * sizeof(uint32_t)));
+        HIPCHK(hipMalloc(&c->d_xpow8, xp.size() * sizeof(uint32_t)));
+        HIPCHK(hipMemcpy(c->d_crc, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->d_xpow8, xp.data(), xp.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     *out = c;
     return OFDMTX_OK;
 }
@@ -678,11 +842,13 @@ int ofdmtx_create(int device, ofdmtx_ctx **out)
 int ofdmtx_destroy(ofdmtx_ctx *c)
 {
     if (!c) return OFDMTX_EINVAL;
-    hipSetDevice(c->device);
-    hipFree(c->d_scr);
-    hipFree(c->d_lut);
-    hipFree(c->d_pre);
-    hipFree(c->d_tw);
+    (void)hipSetDevice(c->device);
+    (void)hipFree(c->d_scr);
+    (void)hipFree(c->d_lut);
+    (void)hipFree(c->d_pre);
+    (void)hipFree(c->d_tw);
+    (void)hipFree(c->d_crc);
+    (void)hipFree(c->d_xpow8);
     delete c;
     return OFDMTX_OK;
 }
@@ -867,10 +1033,10 @@ int ofdmtx_plan_ragged(ofdmtx_ctx *ctx, uint64_t n_pkts, const uint8_t *regimes,
 int ofdmtx_plan_destroy(ofdmtx_plan *pl)
 {
     if (!pl) return OFDMTX_EINVAL;
-    hipSetDevice(pl->ctx->device);
-    if (pl->d_recs) hipFree(pl->d_recs);
-    if (pl->d_row_start) hipFree(pl->d_row_start);
-    if (pl->d_group_pkt) hipFree(pl->d_group_pkt);
+    (void)hipSetDevice(pl->ctx->device);
+    if (pl->d_recs) (void)hipFree(pl->d_recs);
+    if (pl->d_row_start) (void)hipFree(pl->d_row_start);
+    if (pl->d_group_pkt) (void)hipFree(pl->d_group_pkt);
     delete pl;
     return OFDMTX_OK;
 }
