@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libofdmtx.so")
+LIB_PATH = os.environ.get("OFDMTX_LIB", os.path.join(_HERE, "libofdmtx.so"))
 
 OK = 0
 EINVAL, EREGIME, ELENGTH, EHIP, ENOMEM, ESHAPE, ETOOBIG = -1, -2, -3, -4, -5, -6, -7

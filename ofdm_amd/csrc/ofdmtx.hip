@@ -23,6 +23,10 @@
 #include "ofdm_tables.h"
 #include "ofdmtx.h"
 
+#ifndef OFDMTX_EXPERIMENT
+#define OFDMTX_EXPERIMENT 0   // 1: no IQ stores, 2: no symbol compute (timing experiments only)
+#endif
+
 namespace {
 
 thread_local int g_last_hip = 0;
@@ -141,14 +145,15 @@ __device__ inline Pkt load_pkt(const PlanParams &P, uint32_t p)
     return k;
 }
 
-// Lanes of one wavefront exchange data through LDS without a workgroup barrier: LDS
-// operations of a wave execute in program order, so only the compiler has to be kept from
-// moving accesses across the hand-over point.
+// Lanes of one wavefront exchange data through LDS without a workgroup barrier.  LDS
+// operations of a wave execute in issue order, so the hand-over needs (a) the compiler kept
+// from moving LDS accesses across this point ("memory" clobber) and (b) at most a wait for the
+// wave's own LDS operations.  Deliberately NOT a fence: a release fence also drains the
+// vector-memory counter, i.e. it would wait for every global store still in flight.
 __device__ inline void wave_sync()
 {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // ======================================================================================
@@ -545,6 +550,60 @@ __device__ inline int bin_code(int k)
 }
 
 constexpr int MOD_WAVES = 4;
+constexpr int TG = 72;   // float2 per symbol in the transposition layout (8 rows x 9)
+constexpr int RS = 88;   // float2 per row in the staging layout
+
+// Row descriptor packed into one register:
+//   bits 0..1   type (0 preamble, 1 symbol, 2 gap, 3 beyond the end)
+//   bits 2..4   bits per carrier       bits 5..9   bit offset of the lane's window in its first dword
+//   bits 10..16 LUT offset             bit 17      pilot polarity is -1
+//   bits 18..19 preamble row index
+__device__ inline int cw_type(uint32_t cw) { return (int)(cw & 3u); }
+
+// Decode row `grp*8 + g`: returns the descriptor and the address of the lane's 8-byte message
+// window (src).  d0 = first data carrier among the lane's eight bins.
+template <bool UNIFORM>
+__device__ inline uint32_t prepare_row(const PlanParams &P, uint64_t pneg_lo, uint64_t pneg_hi, const uint8_t *msg,
+                                       uint32_t grp, uint32_t n_groups, int g, int d0,
+                                       uint32_t pre_rows, const uint8_t *&src, uint32_t &map_row)
+{
+    src = msg;                     // rows without message bits still load (and ignore) 12 valid bytes
+    map_row = 0;
+    if (grp >= n_groups) return 3u;
+    const uint32_t row = grp * 8u + g;
+    if (row >= P.total_rows) return 3u;
+    uint32_t pkt, r;
+    if (UNIFORM) {
+        pkt = row / P.rows_per_pkt;
+        r = row - pkt * P.rows_per_pkt;
+    } else {
+        pkt = P.group_pkt[grp];
+        while (pkt + 1 < P.n_pkts && row >= P.row_start[pkt + 1]) pkt++;
+        r = row - P.row_start[pkt];
+    }
+    if (r < pre_rows) return 0u | (r << 18);
+    const Pkt k = load_pkt<UNIFORM>(P, pkt);
+    const uint32_t s = r - pre_rows;                                     // symbol index, 0 = SIGNAL
+    if (s > k.n_sym) return 2u;
+    const RegimeInfo ri = regime_info((int)k.regime);
+    const uint32_t nb = s == 0 ? 1u : (uint32_t)ri.n_bpsc;               // ftw/ftw_ofdm_mapper.cc:184-191
+    const uint32_t lut_off = s == 0 ? 0u : (uint32_t)ri.lut_off;
+    const uint32_t bit0 = (s == 0 ? 0u : 48u + (s - 1u) * ri.n_cbps) + (uint32_t)d0 * nb;
+    // up to 7 carriers x 6 bits + 7 bits of misalignment fit in 64 bits
+    // (fetched as three ALIGNED dwords: unaligned 8-byte loads are several times slower)
+    const uint8_t *first = msg + k.msg_off + (bit0 >> 3);
+    const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(first) & 3u);
+    src = first - mis;
+#if OFDMTX_EXPERIMENT == 4
+    src = msg + 16 * g;
+#endif
+    const uint32_t pidx = (k.pilot_base + s) % 127u;                     // ftw/ftw_ofdm_pilot_cc.cc:116
+    // (selects instead of indexing: a dynamically indexed kernel-argument array becomes a
+    //  vector-memory load, and with it a wait for every store in flight)
+    const uint32_t neg = (uint32_t)((pidx < 64u ? pneg_lo : pneg_hi) >> (pidx & 63u)) & 1u;
+    map_row = k.sym_off + s;
+    return 1u | (nb << 2) | ((8u * mis + (bit0 & 7u)) << 5) | (lut_off << 10) | (neg << 17);
+}
 
 template <bool UNIFORM>
 __global__ void __launch_bounds__(64 * MOD_WAVES)
@@ -553,7 +612,12 @@ k_modulate(PlanParams P, DevTables T, const uint8_t *__restrict__ msg, float2 *_
 {
     __shared__ float2 s_lut[LUT_SIZE];
     __shared__ float2 s_pre[PRE_ROWS * SYM_LEN];
-    __shared__ __align__(16) float2 s_buf[MOD_WAVES][8 * SYM_LEN];
+    __shared__ float2 s_tw[64];
+    // Per-wave LDS area, used three times per iteration with two layouts chosen so that every
+    // access pattern below is bank-conflict free (ds_*_b64: 64 banks for reads, 32 for writes):
+    //   transposition layout: element (a,b) of symbol g at TG*g + 9*a + b    (rows of 8 padded to 9)
+    //   staging layout      : sample o of row g at RS*g + o                  (rows of 80 padded to 88)
+    __shared__ __align__(16) float2 s_buf[MOD_WAVES][8 * RS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float amp = P.amp;
@@ -562,79 +626,101 @@ k_modulate(PlanParams P, DevTables T, const uint8_t *__restrict__ msg, float2 *_
         float2 v = T.preamble[i];                         // pu:508 literals as float32 ...
         s_pre[i] = make_float2(v.x * amp, v.y * amp);     // ... times tx_amplitude
     }
+    // twiddles W64^{l*p} of the 8x8 decomposition, entry 8*p + l (lanes of a symbol read 8
+    // consecutive entries, the 8 symbols of a wave read the same ones)
+    for (int i = tid; i < 64; i += 64 * MOD_WAVES) s_tw[i] = T.tw64[((i & 7) * (i >> 3)) & 63];
     __syncthreads();
 
     const int l = lane & 7, g = lane >> 3;
     float2 *buf = s_buf[wave];
     const float scale = 0.125f * amp;   // 1/sqrt(64) is a power of two: (x*0.125)*amp == x*(0.125*amp)
 
-    float2 tw[8];
-#pragma unroll
-    for (int p = 0; p < 8; p++) tw[p] = T.tw64[(l * p) & 63];
-
     // the lane's own eight consecutive bins 8l..8l+7 (mapping stage)
-    int code[8];
-    int d0 = -1, cnt = 0;
+    // kinds: 2 bits per bin -- 0 null, 1 data, 2 pilot +p, 3 pilot -p; d0 = first data carrier
+    uint32_t kinds = 0;
+    int d0 = -1;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        code[i] = bin_code(8 * l + i);
-        if (code[i] >= 0) {
-            if (d0 < 0) d0 = code[i];
-            cnt++;
-        }
+        const int c = bin_code(8 * l + i);
+        if (c >= 0 && d0 < 0) d0 = c;
+        kinds |= (uint32_t)(c >= 0 ? 1 : (c == -1 ? 0 : (c == -2 ? 2 : 3))) << (2 * i);
     }
-    (void)cnt;
+
+    // pilot polarity mask pinned in scalar registers
+    uint64_t pneg_lo = T.pilot_neg[0] | ((uint64_t)T.pilot_neg[1] << 32);
+    uint64_t pneg_hi = T.pilot_neg[2] | ((uint64_t)T.pilot_neg[3] << 32);
+    asm volatile("" : "+s"(pneg_lo), "+s"(pneg_hi));
 
     const uint32_t pre_rows = (P.flags & OFDMTX_F_PREAMBLE) ? PRE_ROWS : 0;
     const uint32_t n_groups = (P.total_rows + 7u) / 8u;
+    const bool swap_iq = (P.flags & OFDMTX_F_SWAPIQ) != 0;
 
-    for (uint32_t grp = blockIdx.x * MOD_WAVES + wave; grp < n_groups; grp += gridDim.x * MOD_WAVES) {
-        const uint32_t row = grp * 8u + g;
-        // ---- which packet / which row of it
-        int type = 3;                                     // 0 preamble, 1 symbol, 2 gap, 3 beyond the end
-        uint32_t pkt = 0, r = 0;
-        Pkt k = {};
-        if (row < P.total_rows) {
-            if (UNIFORM) {
-                pkt = row / P.rows_per_pkt;
-                r = row - pkt * P.rows_per_pkt;
-            } else {
-                pkt = P.group_pkt[grp];
-                while (pkt + 1 < P.n_pkts && row >= P.row_start[pkt + 1]) pkt++;
-                r = row - P.row_start[pkt];
-            }
-            k = load_pkt<UNIFORM>(P, pkt);
-            type = r < pre_rows ? 0 : (r - pre_rows <= k.n_sym ? 1 : 2);
-        }
-        const uint32_t s = r - pre_rows;                  // symbol index, 0 = SIGNAL
+    // Pipeline over groups: the message window of group i+1 is requested one iteration ahead.
+    // Loads and stores share the vector-memory counter and retire in issue order, but hipcc
+    // waits for vmcnt(0) -- i.e. for every store in flight -- whenever it sees a loaded value used
+    // while stores are pending.  The window load is therefore issued from inline asm, invisible
+    // to that pass, and retired by a counted wait: between the load of group i+1 and its first
+    // use exactly the five IQ stores of group i are issued (tap stores, if any, only add to
+    // that), so "vmcnt(5)" is the load's completion.  LOAD_WINDOW / WAIT_WINDOW are the only
+    // places that touch the pending registers.
+#if OFDMTX_EXPERIMENT == 3
+#define LOAD_WINDOW(dst, ptr) asm volatile("v_mov_b32 %0, 0" : "=v"(dst) : "v"(ptr) : "memory")
+#else
+#define LOAD_WINDOW(dst, ptr) asm volatile("global_load_dwordx3 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
+#endif
+#if OFDMTX_EXPERIMENT == 1 || OFDMTX_EXPERIMENT == 3
+#define WAIT_WINDOW(dst) asm volatile("s_waitcnt vmcnt(0)" : "+v"(dst) : : "memory")
+#else
+#define WAIT_WINDOW(dst) asm volatile("s_waitcnt vmcnt(5)" : "+v"(dst) : : "memory")
+#endif
+    const uint32_t grp_stride = gridDim.x * MOD_WAVES;
+    const uint32_t grp0 = blockIdx.x * MOD_WAVES + wave;
+    const uint8_t *src;
+    typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+    // 64 message bits starting at the lane's first wanted bit (that bit at bit 63)
+    auto window = [](u32x3 raw, uint32_t cw) {
+        const uint32_t sh = (cw >> 5) & 31u;
+        const uint32_t b0 = __builtin_bswap32(raw.x), b1 = __builtin_bswap32(raw.y), b2 = __builtin_bswap32(raw.z);
+        return ((uint64_t)__funnelshift_l(b1, b0, sh) << 32) | __funnelshift_l(b2, b1, sh);
+    };
+    u32x3 raw_n;                                          // window of group i+1, in flight
+    uint32_t map_c, map_n;
+    uint32_t cw_c = prepare_row<UNIFORM>(P, pneg_lo, pneg_hi, msg, grp0, n_groups, g, d0, pre_rows, src, map_c);
+    LOAD_WINDOW(raw_n, src);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw_n) : : "memory");
+    uint64_t W_c = window(raw_n, cw_c);
+    uint32_t cw_n = prepare_row<UNIFORM>(P, pneg_lo, pneg_hi, msg, grp0 + grp_stride, n_groups, g, d0, pre_rows, src, map_n);
+    LOAD_WINDOW(raw_n, src);
 
-        // ---- mapper + pilots + carrier map, bins in natural order at buf[g*64 + k]
+    for (uint32_t grp = grp0; grp < n_groups; grp += grp_stride) {
+#if OFDMTX_EXPERIMENT == 2 || OFDMTX_EXPERIMENT == 3 || OFDMTX_EXPERIMENT == 4
+        const int type = P.amp == 12345.f ? cw_type(cw_c) : 2;
+#else
+        const int type = cw_type(cw_c);
+#endif
+
+        // ---- mapper + pilots + carrier map, bins in natural order (transposition layout)
         if (type == 1) {
-            const RegimeInfo ri = regime_info((int)k.regime);
-            const uint32_t nb = s == 0 ? 1u : (uint32_t)ri.n_bpsc;       // ftw/ftw_ofdm_mapper.cc:184-191
-            const uint32_t lut_off = s == 0 ? 0u : (uint32_t)ri.lut_off;
-            const uint32_t bit0 = (s == 0 ? 0u : 48u + (s - 1u) * ri.n_cbps) + (uint32_t)(d0 < 0 ? 0 : d0) * nb;
-            // up to 7 carriers x 6 bits + 7 bits of misalignment fit in 64 bits
-            uint64_t raw;
-            __builtin_memcpy(&raw, msg + k.msg_off + (bit0 >> 3), 8);
-            const uint64_t W = __builtin_bswap64(raw) << (bit0 & 7u);    // first wanted bit at bit 63
-            const uint32_t pidx = (k.pilot_base + s) % 127u;             // ftw/ftw_ofdm_pilot_cc.cc:116
-            const float pil = ((T.pilot_neg[pidx >> 5] >> (pidx & 31u)) & 1u) ? -1.f : 1.f;
-            uint32_t used = 0;
+            const uint32_t nb = (cw_c >> 2) & 7u;
+            const uint32_t lut_off = (cw_c >> 10) & 127u;
+            const float pil = (cw_c >> 17) & 1u ? -1.f : 1.f;
+            uint32_t used = 0, nd = 0;
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 float2 v;
-                if (code[i] >= 0) {
-                    uint32_t idx = (uint32_t)((W << used) >> (64u - nb));
-                    used += nb;
+                const uint32_t kind = (kinds >> (2 * i)) & 3u;
+                if (kind == 1u) {
+                    const uint32_t idx = (uint32_t)((W_c << used) >> (64u - nb));
                     v = s_lut[lut_off + idx];
-                    if (mapped) mapped[((size_t)k.sym_off + s) * 48u + code[i]] = v;
-                } else if (code[i] == -1) {
+                    if (mapped) mapped[(size_t)map_c * 48u + d0 + nd] = v;
+                    used += nb;
+                    nd++;
+                } else if (kind == 0u) {
                     v = make_float2(0.f, 0.f);
                 } else {
-                    v = make_float2(code[i] == -2 ? pil : -pil, 0.f);
+                    v = make_float2(kind == 2u ? pil : -pil, 0.f);
                 }
-                buf[g * 64 + 8 * l + i] = v;
+                buf[g * TG + 9 * l + i] = v;
             }
         }
         wave_sync();
@@ -643,54 +729,89 @@ k_modulate(PlanParams P, DevTables T, const uint8_t *__restrict__ msg, float2 *_
         float2 x[8];
         if (type == 1) {
 #pragma unroll
-            for (int m = 0; m < 8; m++) x[m] = buf[g * 64 + l + 8 * m];
+            for (int m = 0; m < 8; m++) x[m] = buf[g * TG + l + 9 * m];
         }
         wave_sync();
         if (type == 1) {
             idft8(x);
 #pragma unroll
-            for (int p = 1; p < 8; p++) x[p] = cmul(x[p], tw[p]);
+            for (int p = 1; p < 8; p++) x[p] = cmul(x[p], s_tw[8 * p + l]);
 #pragma unroll
-            for (int p = 0; p < 8; p++) buf[g * 64 + 8 * p + l] = x[p];
+            for (int p = 0; p < 8; p++) buf[g * TG + 9 * p + l] = x[p];
         }
         wave_sync();
         if (type == 1) {
 #pragma unroll
-            for (int i = 0; i < 8; i++) x[i] = buf[g * 64 + 8 * l + i];   // lane now plays p = l
+            for (int i = 0; i < 8; i++) x[i] = buf[g * TG + 9 * l + i];   // lane now plays p = l
         }
         wave_sync();
 
-        // ---- the row's 80 samples into the staging area (cyclic prefix: out[o] = x[(o+48)%64])
+        // ---- the row's 80 samples into the staging area.  Lane l owns samples l + 8i, i = 0..9:
+        // symbol rows: out[o] = x[(o + 48) % 64] (cyclic prefix, examples/ftw_ofdm.py:121-123), so
+        // i = 0,1 repeat q = 6,7 and i >= 2 is q = i - 2; preamble rows copy the table, gap rows are 0.
+        float2 o10[10];
         if (type == 1) {
             idft8(x);                                                     // x[q] = sample 8q + l
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-                float2 v = make_float2(x[q].x * scale, x[q].y * scale);
-                buf[g * SYM_LEN + 16 + 8 * q + l] = v;
-                if (q >= 6) buf[g * SYM_LEN + 8 * q + l - 48] = v;
-            }
-        } else if (type == 0) {
+            for (int q = 0; q < 8; q++) x[q] = make_float2(x[q].x * scale, x[q].y * scale);
+            o10[0] = x[6];
+            o10[1] = x[7];
 #pragma unroll
-            for (int i = 0; i < 10; i++) buf[g * SYM_LEN + l + 8 * i] = s_pre[r * SYM_LEN + l + 8 * i];
+            for (int q = 0; q < 8; q++) o10[q + 2] = x[q];
+        } else if (type == 0) {
+            const uint32_t r = cw_c >> 18;
+#pragma unroll
+            for (int i = 0; i < 10; i++) o10[i] = s_pre[r * SYM_LEN + l + 8 * i];
         } else {
 #pragma unroll
-            for (int i = 0; i < 10; i++) buf[g * SYM_LEN + l + 8 * i] = make_float2(0.f, 0.f);
+            for (int i = 0; i < 10; i++) o10[i] = make_float2(0.f, 0.f);
         }
+        if (swap_iq) {                                                    // examples/ftw_ofdm.py:155-163
+#pragma unroll
+            for (int i = 0; i < 10; i++) o10[i] = make_float2(o10[i].y, o10[i].x);
+        }
+#pragma unroll
+        for (int i = 0; i < 10; i++) buf[g * RS + l + 8 * i] = o10[i];
         wave_sync();
 
-        // ---- 8 rows = 5120 contiguous bytes, 16 B per lane per store
+        // ---- 8 rows = 5120 contiguous bytes, 16 B per lane per store: always five store
+        // instructions per iteration (WAIT_WINDOW counts them); lanes beyond the end of the
+        // stream are masked, which happens in the last group only
         float4 *dst = reinterpret_cast<float4 *>(iq + (size_t)grp * 8u * SYM_LEN);
-        const float4 *src = reinterpret_cast<const float4 *>(buf);
         const uint32_t rows_here = P.total_rows - grp * 8u < 8u ? P.total_rows - grp * 8u : 8u;
+        if (rows_here == 8u) {
 #pragma unroll
-        for (int i = 0; i < 5; i++) {
-            int e = i * 64 + lane;                        // float4 index, 40 per row
-            float4 v = src[e];
-            if (P.flags & OFDMTX_F_SWAPIQ) v = make_float4(v.y, v.x, v.w, v.z);
-            if ((uint32_t)e < rows_here * 40u) dst[e] = v;
+            for (int i = 0; i < 5; i++) {
+                const int e = i * 64 + lane;              // float4 index, 40 per row
+#if OFDMTX_EXPERIMENT == 1
+                float4 vv = *reinterpret_cast<const float4 *>(buf + (e / 40) * RS + (e % 40) * 2);
+                asm volatile("" : : "v"(vv.x), "v"(vv.y), "v"(vv.z), "v"(vv.w));
+#else
+                dst[e] = *reinterpret_cast<const float4 *>(buf + (e / 40) * RS + (e % 40) * 2);
+#endif
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                const int e = i * 64 + lane;
+                if ((uint32_t)e < rows_here * 40u)
+                    dst[e] = *reinterpret_cast<const float4 *>(buf + (e / 40) * RS + (e % 40) * 2);
+            }
+        }
+
+        // ---- rotate the pipeline: retire the window of the next group, request the one after
+        if (grp + grp_stride < n_groups) {
+            WAIT_WINDOW(raw_n);
+            cw_c = cw_n;
+            map_c = map_n;
+            W_c = window(raw_n, cw_n);
+            cw_n = prepare_row<UNIFORM>(P, pneg_lo, pneg_hi, msg, grp + 2u * grp_stride, n_groups, g, d0, pre_rows, src, map_n);
+            LOAD_WINDOW(raw_n, src);
         }
         wave_sync();
     }
+#undef LOAD_WINDOW
+#undef WAIT_WINDOW
 }
 
 }  // namespace
