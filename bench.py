@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--packets", type=int, default=1_000_000, help="packets per GPU per step")
+    ap.add_argument("--fused", type=int, default=0, help="1: single fused kernel (ofdmtx_tx), 0: two kernels")
     ap.add_argument("--cpu-sample", type=int, default=40_000, help="packets timed on the CPU baseline (0 = skip)")
     a = ap.parse_args()
 
@@ -103,6 +104,14 @@ def main():
     iq = plan.alloc_iq()
 
     def step(events=None):
+        if a.fused:
+            if events is not None:
+                events[0].record()
+                events[1].record()
+            plan.tx(payloads, out=iq, work=msg)
+            if events is not None:
+                events[2].record()
+            return
         if events is not None:
             events[0].record()
         plan.encode_bits(payloads, out=msg)

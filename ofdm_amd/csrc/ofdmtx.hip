@@ -23,10 +23,6 @@
 #include "ofdm_tables.h"
 #include "ofdmtx.h"
 
-#ifndef OFDMTX_EXPERIMENT
-#define OFDMTX_EXPERIMENT 0   // 1: no IQ stores, 2: no symbol compute (timing experiments only)
-#endif
-
 namespace {
 
 thread_local int g_last_hip = 0;
@@ -339,6 +335,144 @@ __device__ inline void encode_data_symbols(const uint32_t *U, uint32_t *OUTW, ui
     }
 }
 
+// Steps 1-5 for one packet, executed by one wavefront.  A: >= max(n_words + 3, message words + 4)
+// words of LDS (first the natural-order MPDU, finally the message words OUTW: OUTW[0] low half
+// and OUTW[1] = the 48 SIGNAL bits, OUTW[2..] = interleaved DATA bits, all MSB first);
+// U: >= n_words + 2 words.  plcp_out / scr_out / cod_out are optional taps (global memory).
+__device__ inline void encode_packet(const Pkt &k, const RegimeInfo &ri, const DevTables &T,
+                                     const uint8_t *__restrict__ payloads, uint32_t *A, uint32_t *U,
+                                     const uint32_t *s_crc, const uint32_t *s_scr, int lane,
+                                     uint8_t *plcp_out, uint8_t *scr_out, uint8_t *cod_out)
+{
+    const uint32_t mpdu_len = 24u + k.pay_len;
+    const uint32_t length = mpdu_len + 4u;                                   // pu:193
+    const uint32_t n_pad = k.n_sym * ri.n_dbps - (54u + 8u * mpdu_len);      // pu:97
+    const uint32_t plcp_len = 5u + length + (n_pad + 13u) / 8u;              // pu:160-171
+    const uint32_t n_words = (plcp_len + 3u) / 4u;                           // stream words
+    const uint32_t n_dw = (mpdu_len + 3u) / 4u;                              // MPDU dwords
+
+    // ---- 1. MPDU in natural byte order (pu:28-36,100), Dw[-2], Dw[-1] and the tail zero
+    uint32_t *Dw = A + 2;
+    {
+        const uintptr_t ad = reinterpret_cast<uintptr_t>(payloads + k.pay_off);
+        const uint32_t a = (uint32_t)(ad & 3u);
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(ad - a);
+        for (uint32_t i = lane; i < n_words + 3u; i += 64) {
+            const int idx = (int)i - 2;
+            uint32_t v = 0;
+            if (idx >= 6 && (uint32_t)idx < n_dw) {
+                const uint32_t j = (uint32_t)idx - 6u;
+                const uint32_t nb = k.pay_len - 4u * j < 4u ? k.pay_len - 4u * j : 4u;
+                const uint32_t lo = q[j];
+                const uint32_t hi = (a + nb > 4u) ? q[j + 1] : 0u;
+                v = (uint32_t)((((uint64_t)hi << 32) | lo) >> (8u * a));
+                if (nb < 4u) v &= (1u << (8u * nb)) - 1u;
+            } else if (idx >= 0 && idx < 6) {
+                switch (idx) {
+                case 0: v = 0x00000008u | ((k.txtime >> 8) & 0xFFu) << 16 | (k.txtime & 0xFFu) << 24; break;  // pu:91
+                case 1: v = 0xcd086000u; break;
+                case 2: v = 0x2000a637u; break;
+                case 3: v = 0xf13c01d6u; break;
+                case 4: v = 0xad086000u; break;
+                default: v = 0x0000af3bu; break;
+                }
+            }
+            A[i] = v;
+        }
+    }
+    wave_sync();
+
+    // ---- 2. CRC-32 of the MPDU (ftw/ftw_crc32.cc:52-57)
+    uint32_t fcs;
+    {
+        const uint32_t c4 = (n_dw + 63u) / 64u;
+        const uint32_t j0 = lane * c4;
+        uint32_t st = lane == 0 ? 0xFFFFFFFFu : 0u;
+        for (uint32_t j = j0; j < j0 + c4; j++) {
+            if (4u * j + 4u <= mpdu_len) {
+                st ^= Dw[j];
+                st = s_crc[768 + (st & 0xFFu)] ^ s_crc[512 + ((st >> 8) & 0xFFu)] ^
+                     s_crc[256 + ((st >> 16) & 0xFFu)] ^ s_crc[st >> 24];
+            } else if (4u * j < mpdu_len) {
+                const uint32_t d = Dw[j];
+                for (uint32_t b = 0; b < mpdu_len - 4u * j; b++)
+                    st = (st >> 8) ^ s_crc[(st ^ (d >> (8u * b))) & 0xFFu];
+            }
+        }
+        const uint32_t endb = 4u * (j0 + c4) < mpdu_len ? 4u * (j0 + c4) : mpdu_len;
+        uint32_t part = crc_mulmod(st, T.xpow8[mpdu_len - endb]);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) part ^= __shfl_xor(part, off);
+        fcs = __brev(part) ^ 0xFFFFFFFFu;      // state bit-reversed, then ^~0 (ftw/ftw_crc32.cc:58-63,75)
+    }
+
+    // ---- 3. PLCP stream words (pu:128-205) and scrambler (pu:344-367)
+    {
+        const uint32_t rev = __brev(length) >> 20;                           // pu:147-150
+        const uint32_t par = (__popc(rev & 0xFFFu) + __popc((uint32_t)ri.rate_bits)) & 1u;   // pu:153-157
+        const uint32_t field = ((uint32_t)ri.rate_bits << 20) | ((rev & 0xFFFu) << 7) | (par << 6);
+        const uint32_t F = 5u + mpdu_len, wf = F >> 2, fsh = 8u * (F & 3u);
+        const uint32_t tz = 40u + 8u * length;                               // first tail bit
+        for (uint32_t w = lane; w <= n_words; w += 64) {
+            // MPDU bytes 4w-5 .. 4w-2, bit order reversed inside every byte (pu:208-218)
+            uint32_t v = __brev((Dw[(int)w - 2] >> 24) | (Dw[(int)w - 1] << 8));
+            if (w == 0) v |= field << 8;                                     // SIGNAL; SERVICE = 0 (pu:183)
+            if (w == wf) v |= fcs >> fsh;                                    // FCS big-endian (pu:372)
+            if (w == wf + 1u && fsh) v |= fcs << (32u - fsh);
+            if (plcp_out && 4u * w < plcp_len)
+                *reinterpret_cast<uint32_t *>(plcp_out + k.plcp_off + 4u * w) = __builtin_bswap32(v);
+            if (w == 0)
+                v ^= s_scr[0] >> 24;                  // bits 24..31 are SERVICE bits 0..7
+            else
+                v ^= s_scr[(32u * w - 24u) % 127u];
+            if (w == (tz >> 5)) v &= ~(0x3Fu << (26u - (tz & 31u)));         // six tail bits to 0, pu:361-362
+            U[w] = v;
+            if (scr_out && 4u * w < plcp_len)
+                *reinterpret_cast<uint32_t *>(scr_out + k.plcp_off + 4u * w) = __builtin_bswap32(v);
+        }
+    }
+    wave_sync();
+
+    // ---- 4. SIGNAL symbol: 48 coded bits, N = 48 first permutation only (pu:245-249)
+    uint32_t *OUTW = A;
+    uint8_t *co = cod_out ? cod_out + k.msg_off : nullptr;
+    {
+        const uint32_t t = 63u - lane;                // ballot bit `lane` = stream bit 63 - lane
+        uint32_t bi = 0, bc = 0;
+        if (t < 48u) {
+            bi = coded_bit(U, 16u * (t % 3u) + t / 3u);
+            bc = coded_bit(U, t);
+        }
+        const unsigned long long mi = __ballot(bi);
+        const unsigned long long mc = __ballot(bc);
+        const uint32_t ndw = (k.n_sym * ri.n_cbps) >> 5;      // whole DATA words
+        if (lane == 0) {
+            OUTW[0] = (uint32_t)(mi >> 48);
+            OUTW[1] = (uint32_t)(mi >> 16);
+            OUTW[2u + ndw] = 0;                       // partly filled / trailing words
+            OUTW[3u + ndw] = 0;
+            if (co) {
+#pragma unroll
+                for (int b = 0; b < 6; b++) co[b] = (uint8_t)(mc >> (56 - 8 * b));
+            }
+        }
+    }
+
+    // ---- 5. DATA symbols
+    switch (k.regime) {
+    case 1: encode_data_symbols<1, 0>(U, OUTW, k.n_sym, co, lane); break;
+    case 2: encode_data_symbols<1, 1>(U, OUTW, k.n_sym, co, lane); break;
+    case 3: encode_data_symbols<2, 0>(U, OUTW, k.n_sym, co, lane); break;
+    case 4: encode_data_symbols<2, 1>(U, OUTW, k.n_sym, co, lane); break;
+    case 5: encode_data_symbols<4, 0>(U, OUTW, k.n_sym, co, lane); break;
+    case 6: encode_data_symbols<4, 1>(U, OUTW, k.n_sym, co, lane); break;
+    case 7: encode_data_symbols<6, 2>(U, OUTW, k.n_sym, co, lane); break;
+    default: encode_data_symbols<6, 1>(U, OUTW, k.n_sym, co, lane); break;
+    }
+    wave_sync();
+
+}
+
 constexpr int ENC_WAVES = 4;
 constexpr int ENC_A_WORDS = 1600;   // natural MPDU (2 zero words + <= 792 words), later the message words
 constexpr int ENC_U_WORDS = MAX_PLCP / 4 + 4;
@@ -365,133 +499,9 @@ k_encode_bits(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads,
     for (uint32_t p = blockIdx.x * ENC_WAVES + wave; p < P.n_pkts; p += gridDim.x * ENC_WAVES) {
         const Pkt k = load_pkt<UNIFORM>(P, p);
         const RegimeInfo ri = regime_info((int)k.regime);
-        const uint32_t mpdu_len = 24u + k.pay_len;
-        const uint32_t length = mpdu_len + 4u;                                   // pu:193
-        const uint32_t n_pad = k.n_sym * ri.n_dbps - (54u + 8u * mpdu_len);      // pu:97
-        const uint32_t plcp_len = 5u + length + (n_pad + 13u) / 8u;              // pu:160-171
-        const uint32_t n_words = (plcp_len + 3u) / 4u;                           // stream words
-        const uint32_t n_dw = (mpdu_len + 3u) / 4u;                              // MPDU dwords
         const uint32_t msg_len = 6u + k.n_sym * ri.n_cbps / 8u;
-
-        // ---- 1. MPDU in natural byte order (pu:28-36,100), Dw[-2], Dw[-1] and the tail zero
-        uint32_t *Dw = A + 2;
-        {
-            const uintptr_t ad = reinterpret_cast<uintptr_t>(payloads + k.pay_off);
-            const uint32_t a = (uint32_t)(ad & 3u);
-            const uint32_t *q = reinterpret_cast<const uint32_t *>(ad - a);
-            for (uint32_t i = lane; i < n_words + 3u; i += 64) {
-                const int idx = (int)i - 2;
-                uint32_t v = 0;
-                if (idx >= 6 && (uint32_t)idx < n_dw) {
-                    const uint32_t j = (uint32_t)idx - 6u;
-                    const uint32_t nb = k.pay_len - 4u * j < 4u ? k.pay_len - 4u * j : 4u;
-                    const uint32_t lo = q[j];
-                    const uint32_t hi = (a + nb > 4u) ? q[j + 1] : 0u;
-                    v = (uint32_t)((((uint64_t)hi << 32) | lo) >> (8u * a));
-                    if (nb < 4u) v &= (1u << (8u * nb)) - 1u;
-                } else if (idx >= 0 && idx < 6) {
-                    switch (idx) {
-                    case 0: v = 0x00000008u | ((k.txtime >> 8) & 0xFFu) << 16 | (k.txtime & 0xFFu) << 24; break;  // pu:91
-                    case 1: v = 0xcd086000u; break;
-                    case 2: v = 0x2000a637u; break;
-                    case 3: v = 0xf13c01d6u; break;
-                    case 4: v = 0xad086000u; break;
-                    default: v = 0x0000af3bu; break;
-                    }
-                }
-                A[i] = v;
-            }
-        }
-        wave_sync();
-
-        // ---- 2. CRC-32 of the MPDU (ftw/ftw_crc32.cc:52-57)
-        uint32_t fcs;
-        {
-            const uint32_t c4 = (n_dw + 63u) / 64u;
-            const uint32_t j0 = lane * c4;
-            uint32_t st = lane == 0 ? 0xFFFFFFFFu : 0u;
-            for (uint32_t j = j0; j < j0 + c4; j++) {
-                if (4u * j + 4u <= mpdu_len) {
-                    st ^= Dw[j];
-                    st = s_crc[768 + (st & 0xFFu)] ^ s_crc[512 + ((st >> 8) & 0xFFu)] ^
-                         s_crc[256 + ((st >> 16) & 0xFFu)] ^ s_crc[st >> 24];
-                } else if (4u * j < mpdu_len) {
-                    const uint32_t d = Dw[j];
-                    for (uint32_t b = 0; b < mpdu_len - 4u * j; b++)
-                        st = (st >> 8) ^ s_crc[(st ^ (d >> (8u * b))) & 0xFFu];
-                }
-            }
-            const uint32_t endb = 4u * (j0 + c4) < mpdu_len ? 4u * (j0 + c4) : mpdu_len;
-            uint32_t part = crc_mulmod(st, T.xpow8[mpdu_len - endb]);
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) part ^= __shfl_xor(part, off);
-            fcs = __brev(part) ^ 0xFFFFFFFFu;      // state bit-reversed, then ^~0 (ftw/ftw_crc32.cc:58-63,75)
-        }
-
-        // ---- 3. PLCP stream words (pu:128-205) and scrambler (pu:344-367)
-        {
-            const uint32_t rev = __brev(length) >> 20;                           // pu:147-150
-            const uint32_t par = (__popc(rev & 0xFFFu) + __popc((uint32_t)ri.rate_bits)) & 1u;   // pu:153-157
-            const uint32_t field = ((uint32_t)ri.rate_bits << 20) | ((rev & 0xFFFu) << 7) | (par << 6);
-            const uint32_t F = 5u + mpdu_len, wf = F >> 2, fsh = 8u * (F & 3u);
-            const uint32_t tz = 40u + 8u * length;                               // first tail bit
-            for (uint32_t w = lane; w <= n_words; w += 64) {
-                // MPDU bytes 4w-5 .. 4w-2, bit order reversed inside every byte (pu:208-218)
-                uint32_t v = __brev((Dw[(int)w - 2] >> 24) | (Dw[(int)w - 1] << 8));
-                if (w == 0) v |= field << 8;                                     // SIGNAL; SERVICE = 0 (pu:183)
-                if (w == wf) v |= fcs >> fsh;                                    // FCS big-endian (pu:372)
-                if (w == wf + 1u && fsh) v |= fcs << (32u - fsh);
-                if (plcp_out && 4u * w < plcp_len)
-                    *reinterpret_cast<uint32_t *>(plcp_out + k.plcp_off + 4u * w) = __builtin_bswap32(v);
-                if (w == 0)
-                    v ^= s_scr[0] >> 24;                  // bits 24..31 are SERVICE bits 0..7
-                else
-                    v ^= s_scr[(32u * w - 24u) % 127u];
-                if (w == (tz >> 5)) v &= ~(0x3Fu << (26u - (tz & 31u)));         // six tail bits to 0, pu:361-362
-                U[w] = v;
-                if (scr_out && 4u * w < plcp_len)
-                    *reinterpret_cast<uint32_t *>(scr_out + k.plcp_off + 4u * w) = __builtin_bswap32(v);
-            }
-        }
-        wave_sync();
-
-        // ---- 4. SIGNAL symbol: 48 coded bits, N = 48 first permutation only (pu:245-249)
+        encode_packet(k, ri, T, payloads, A, U, s_crc, s_scr, lane, plcp_out, scr_out, cod_out);
         uint32_t *OUTW = A;
-        uint8_t *co = cod_out ? cod_out + k.msg_off : nullptr;
-        {
-            const uint32_t t = 63u - lane;                // ballot bit `lane` = stream bit 63 - lane
-            uint32_t bi = 0, bc = 0;
-            if (t < 48u) {
-                bi = coded_bit(U, 16u * (t % 3u) + t / 3u);
-                bc = coded_bit(U, t);
-            }
-            const unsigned long long mi = __ballot(bi);
-            const unsigned long long mc = __ballot(bc);
-            const uint32_t ndw = (k.n_sym * ri.n_cbps) >> 5;      // whole DATA words
-            if (lane == 0) {
-                OUTW[0] = (uint32_t)(mi >> 48);
-                OUTW[1] = (uint32_t)(mi >> 16);
-                OUTW[2u + ndw] = 0;                       // partly filled / trailing words
-                OUTW[3u + ndw] = 0;
-                if (co) {
-#pragma unroll
-                    for (int b = 0; b < 6; b++) co[b] = (uint8_t)(mc >> (56 - 8 * b));
-                }
-            }
-        }
-
-        // ---- 5. DATA symbols
-        switch (k.regime) {
-        case 1: encode_data_symbols<1, 0>(U, OUTW, k.n_sym, co, lane); break;
-        case 2: encode_data_symbols<1, 1>(U, OUTW, k.n_sym, co, lane); break;
-        case 3: encode_data_symbols<2, 0>(U, OUTW, k.n_sym, co, lane); break;
-        case 4: encode_data_symbols<2, 1>(U, OUTW, k.n_sym, co, lane); break;
-        case 5: encode_data_symbols<4, 0>(U, OUTW, k.n_sym, co, lane); break;
-        case 6: encode_data_symbols<4, 1>(U, OUTW, k.n_sym, co, lane); break;
-        case 7: encode_data_symbols<6, 2>(U, OUTW, k.n_sym, co, lane); break;
-        default: encode_data_symbols<6, 1>(U, OUTW, k.n_sym, co, lane); break;
-        }
-        wave_sync();
 
         // ---- 6. message bytes = OUTW stream shifted by 16 bits (6 SIGNAL bytes lead)
         {
@@ -549,9 +559,114 @@ __device__ inline int bin_code(int k)
     return t - (t > 5) - (t > 19) - (t > 26) - (t > 33) - (t > 47);
 }
 
-constexpr int MOD_WAVES = 4;
 constexpr int TG = 72;   // float2 per symbol in the transposition layout (8 rows x 9)
 constexpr int RS = 88;   // float2 per row in the staging layout
+
+// One group of 8 consecutive output rows by one wavefront, 8 lanes per row (lane = 8*g + l):
+// mapping -> 64-point inverse DFT -> cyclic prefix / preamble / gap -> coalesced stores.
+//   type 0 preamble row `pre_row`, 1 OFDM symbol, 2 zero-gap row, 3 no row
+//   W     the lane's 64 message bits, first wanted bit at bit 63 (bins 8l..8l+7, nb bits each)
+//   kinds 2 bits per bin: 0 null, 1 data, 2 pilot +p, 3 pilot -p; d0 = first data carrier of the lane
+//   buf   the wave's LDS area of 8*RS float2; dst = first of the group's `rows_here` rows
+__device__ inline void modulate_group(int type, uint32_t pre_row, uint64_t W, uint32_t nb, uint32_t lut_off,
+                                      float pil, uint32_t map_row, float2 *__restrict__ mapped,
+                                      uint32_t kinds, int d0, int l, int g, int lane, float2 *buf,
+                                      const float2 *s_lut, const float2 *s_pre, const float2 *s_tw,
+                                      float scale, bool swap_iq, float4 *__restrict__ dst, uint32_t rows_here)
+{
+    // ---- mapper + pilots + carrier map, bins in natural order (transposition layout)
+    if (type == 1) {
+        uint32_t used = 0, nd = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            float2 v;
+            const uint32_t kind = (kinds >> (2 * i)) & 3u;
+            if (kind == 1u) {
+                const uint32_t idx = (uint32_t)((W << used) >> (64u - nb));
+                v = s_lut[lut_off + idx];
+                if (mapped) mapped[(size_t)map_row * 48u + d0 + nd] = v;
+                used += nb;
+                nd++;
+            } else if (kind == 0u) {
+                v = make_float2(0.f, 0.f);
+            } else {
+                v = make_float2(kind == 2u ? pil : -pil, 0.f);
+            }
+            buf[g * TG + 9 * l + i] = v;
+        }
+    }
+    wave_sync();
+
+    // ---- 64-point inverse DFT as 8 x 8: x[8q+p] = sum_l W8^{lq} W64^{lp} sum_m X[l+8m] W8^{mp}
+    float2 x[8];
+    if (type == 1) {
+#pragma unroll
+        for (int m = 0; m < 8; m++) x[m] = buf[g * TG + l + 9 * m];
+    }
+    wave_sync();
+    if (type == 1) {
+        idft8(x);
+#pragma unroll
+        for (int p = 1; p < 8; p++) x[p] = cmul(x[p], s_tw[8 * p + l]);
+#pragma unroll
+        for (int p = 0; p < 8; p++) buf[g * TG + 9 * p + l] = x[p];
+    }
+    wave_sync();
+    if (type == 1) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) x[i] = buf[g * TG + 9 * l + i];   // lane now plays p = l
+    }
+    wave_sync();
+
+    // ---- the row's 80 samples into the staging area.  Lane l owns samples l + 8i, i = 0..9:
+    // symbol rows: out[o] = x[(o + 48) % 64] (cyclic prefix, examples/ftw_ofdm.py:121-123), so
+    // i = 0,1 repeat q = 6,7 and i >= 2 is q = i - 2; preamble rows copy the table, gap rows are 0.
+    float2 o10[10];
+    if (type == 1) {
+        idft8(x);                                                     // x[q] = sample 8q + l
+#pragma unroll
+        for (int q = 0; q < 8; q++) x[q] = make_float2(x[q].x * scale, x[q].y * scale);
+        o10[0] = x[6];
+        o10[1] = x[7];
+#pragma unroll
+        for (int q = 0; q < 8; q++) o10[q + 2] = x[q];
+    } else if (type == 0) {
+        const uint32_t r = pre_row;
+#pragma unroll
+        for (int i = 0; i < 10; i++) o10[i] = s_pre[r * SYM_LEN + l + 8 * i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 10; i++) o10[i] = make_float2(0.f, 0.f);
+    }
+    if (swap_iq) {                                                    // examples/ftw_ofdm.py:155-163
+#pragma unroll
+        for (int i = 0; i < 10; i++) o10[i] = make_float2(o10[i].y, o10[i].x);
+    }
+#pragma unroll
+    for (int i = 0; i < 10; i++) buf[g * RS + l + 8 * i] = o10[i];
+    wave_sync();
+
+    // ---- 8 rows = 5120 contiguous bytes, 16 B per lane per store: always five store
+    // instructions per iteration (WAIT_WINDOW counts them); lanes beyond the end of the
+    // stream are masked, which happens in the last group only
+    if (rows_here == 8u) {
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            const int e = i * 64 + lane;              // float4 index, 40 per row
+            dst[e] = *reinterpret_cast<const float4 *>(buf + (e / 40) * RS + (e % 40) * 2);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            const int e = i * 64 + lane;
+            if ((uint32_t)e < rows_here * 40u)
+                dst[e] = *reinterpret_cast<const float4 *>(buf + (e / 40) * RS + (e % 40) * 2);
+        }
+    }
+
+}
+
+constexpr int MOD_WAVES = 4;
 
 // Row descriptor packed into one register:
 //   bits 0..1   type (0 preamble, 1 symbol, 2 gap, 3 beyond the end)
@@ -594,9 +709,6 @@ __device__ inline uint32_t prepare_row(const PlanParams &P, uint64_t pneg_lo, ui
     const uint8_t *first = msg + k.msg_off + (bit0 >> 3);
     const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(first) & 3u);
     src = first - mis;
-#if OFDMTX_EXPERIMENT == 4
-    src = msg + 16 * g;
-#endif
     const uint32_t pidx = (k.pilot_base + s) % 127u;                     // ftw/ftw_ofdm_pilot_cc.cc:116
     // (selects instead of indexing: a dynamically indexed kernel-argument array becomes a
     //  vector-memory load, and with it a wait for every store in flight)
@@ -663,16 +775,8 @@ k_modulate(PlanParams P, DevTables T, const uint8_t *__restrict__ msg, float2 *_
     // use exactly the five IQ stores of group i are issued (tap stores, if any, only add to
     // that), so "vmcnt(5)" is the load's completion.  LOAD_WINDOW / WAIT_WINDOW are the only
     // places that touch the pending registers.
-#if OFDMTX_EXPERIMENT == 3
-#define LOAD_WINDOW(dst, ptr) asm volatile("v_mov_b32 %0, 0" : "=v"(dst) : "v"(ptr) : "memory")
-#else
 #define LOAD_WINDOW(dst, ptr) asm volatile("global_load_dwordx3 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
-#endif
-#if OFDMTX_EXPERIMENT == 1 || OFDMTX_EXPERIMENT == 3
-#define WAIT_WINDOW(dst) asm volatile("s_waitcnt vmcnt(0)" : "+v"(dst) : : "memory")
-#else
 #define WAIT_WINDOW(dst) asm volatile("s_waitcnt vmcnt(5)" : "+v"(dst) : : "memory")
-#endif
     const uint32_t grp_stride = gridDim.x * MOD_WAVES;
     const uint32_t grp0 = blockIdx.x * MOD_WAVES + wave;
     const uint8_t *src;
@@ -693,111 +797,12 @@ k_modulate(PlanParams P, DevTables T, const uint8_t *__restrict__ msg, float2 *_
     LOAD_WINDOW(raw_n, src);
 
     for (uint32_t grp = grp0; grp < n_groups; grp += grp_stride) {
-#if OFDMTX_EXPERIMENT == 2 || OFDMTX_EXPERIMENT == 3 || OFDMTX_EXPERIMENT == 4
-        const int type = P.amp == 12345.f ? cw_type(cw_c) : 2;
-#else
         const int type = cw_type(cw_c);
-#endif
 
-        // ---- mapper + pilots + carrier map, bins in natural order (transposition layout)
-        if (type == 1) {
-            const uint32_t nb = (cw_c >> 2) & 7u;
-            const uint32_t lut_off = (cw_c >> 10) & 127u;
-            const float pil = (cw_c >> 17) & 1u ? -1.f : 1.f;
-            uint32_t used = 0, nd = 0;
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                float2 v;
-                const uint32_t kind = (kinds >> (2 * i)) & 3u;
-                if (kind == 1u) {
-                    const uint32_t idx = (uint32_t)((W_c << used) >> (64u - nb));
-                    v = s_lut[lut_off + idx];
-                    if (mapped) mapped[(size_t)map_c * 48u + d0 + nd] = v;
-                    used += nb;
-                    nd++;
-                } else if (kind == 0u) {
-                    v = make_float2(0.f, 0.f);
-                } else {
-                    v = make_float2(kind == 2u ? pil : -pil, 0.f);
-                }
-                buf[g * TG + 9 * l + i] = v;
-            }
-        }
-        wave_sync();
-
-        // ---- 64-point inverse DFT as 8 x 8: x[8q+p] = sum_l W8^{lq} W64^{lp} sum_m X[l+8m] W8^{mp}
-        float2 x[8];
-        if (type == 1) {
-#pragma unroll
-            for (int m = 0; m < 8; m++) x[m] = buf[g * TG + l + 9 * m];
-        }
-        wave_sync();
-        if (type == 1) {
-            idft8(x);
-#pragma unroll
-            for (int p = 1; p < 8; p++) x[p] = cmul(x[p], s_tw[8 * p + l]);
-#pragma unroll
-            for (int p = 0; p < 8; p++) buf[g * TG + 9 * p + l] = x[p];
-        }
-        wave_sync();
-        if (type == 1) {
-#pragma unroll
-            for (int i = 0; i < 8; i++) x[i] = buf[g * TG + 9 * l + i];   // lane now plays p = l
-        }
-        wave_sync();
-
-        // ---- the row's 80 samples into the staging area.  Lane l owns samples l + 8i, i = 0..9:
-        // symbol rows: out[o] = x[(o + 48) % 64] (cyclic prefix, examples/ftw_ofdm.py:121-123), so
-        // i = 0,1 repeat q = 6,7 and i >= 2 is q = i - 2; preamble rows copy the table, gap rows are 0.
-        float2 o10[10];
-        if (type == 1) {
-            idft8(x);                                                     // x[q] = sample 8q + l
-#pragma unroll
-            for (int q = 0; q < 8; q++) x[q] = make_float2(x[q].x * scale, x[q].y * scale);
-            o10[0] = x[6];
-            o10[1] = x[7];
-#pragma unroll
-            for (int q = 0; q < 8; q++) o10[q + 2] = x[q];
-        } else if (type == 0) {
-            const uint32_t r = cw_c >> 18;
-#pragma unroll
-            for (int i = 0; i < 10; i++) o10[i] = s_pre[r * SYM_LEN + l + 8 * i];
-        } else {
-#pragma unroll
-            for (int i = 0; i < 10; i++) o10[i] = make_float2(0.f, 0.f);
-        }
-        if (swap_iq) {                                                    // examples/ftw_ofdm.py:155-163
-#pragma unroll
-            for (int i = 0; i < 10; i++) o10[i] = make_float2(o10[i].y, o10[i].x);
-        }
-#pragma unroll
-        for (int i = 0; i < 10; i++) buf[g * RS + l + 8 * i] = o10[i];
-        wave_sync();
-
-        // ---- 8 rows = 5120 contiguous bytes, 16 B per lane per store: always five store
-        // instructions per iteration (WAIT_WINDOW counts them); lanes beyond the end of the
-        // stream are masked, which happens in the last group only
-        float4 *dst = reinterpret_cast<float4 *>(iq + (size_t)grp * 8u * SYM_LEN);
-        const uint32_t rows_here = P.total_rows - grp * 8u < 8u ? P.total_rows - grp * 8u : 8u;
-        if (rows_here == 8u) {
-#pragma unroll
-            for (int i = 0; i < 5; i++) {
-                const int e = i * 64 + lane;              // float4 index, 40 per row
-#if OFDMTX_EXPERIMENT == 1
-                float4 vv = *reinterpret_cast<const float4 *>(buf + (e / 40) * RS + (e % 40) * 2);
-                asm volatile("" : : "v"(vv.x), "v"(vv.y), "v"(vv.z), "v"(vv.w));
-#else
-                dst[e] = *reinterpret_cast<const float4 *>(buf + (e / 40) * RS + (e % 40) * 2);
-#endif
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 5; i++) {
-                const int e = i * 64 + lane;
-                if ((uint32_t)e < rows_here * 40u)
-                    dst[e] = *reinterpret_cast<const float4 *>(buf + (e / 40) * RS + (e % 40) * 2);
-            }
-        }
+        modulate_group(type, cw_c >> 18, W_c, (cw_c >> 2) & 7u, (cw_c >> 10) & 127u,
+                       (cw_c >> 17) & 1u ? -1.f : 1.f, map_c, mapped, kinds, d0, l, g, lane, buf, s_lut, s_pre,
+                       s_tw, scale, swap_iq, reinterpret_cast<float4 *>(iq + (size_t)grp * 8u * SYM_LEN),
+                       P.total_rows - grp * 8u < 8u ? P.total_rows - grp * 8u : 8u);
 
         // ---- rotate the pipeline: retire the window of the next group, request the one after
         if (grp + grp_stride < n_groups) {
@@ -812,6 +817,99 @@ k_modulate(PlanParams P, DevTables T, const uint8_t *__restrict__ msg, float2 *_
     }
 #undef LOAD_WINDOW
 #undef WAIT_WINDOW
+}
+
+// ======================================================================================
+// Fused kernel: payload -> IQ, one wavefront per packet
+// ======================================================================================
+//
+// The wavefront encodes its packet into LDS (encode_packet) and then emits the packet's rows
+// group by group (modulate_group), taking the mapper's bits straight from the message words
+// in LDS.  Per packet the only HBM traffic is the payload read and the IQ rows written.
+// Dynamic LDS per wave: a_words (MPDU / message words) + 8*RS float2 (scrambled words during
+// encoding, FFT transposition and row staging afterwards).
+
+constexpr int TX_WAVES = 4;
+constexpr int TX_B_WORDS = 8 * RS * 2;
+
+template <bool UNIFORM>
+__global__ void __launch_bounds__(64 * TX_WAVES)
+k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads, float2 *__restrict__ iq,
+     uint32_t a_words)
+{
+    extern __shared__ __align__(16) uint32_t s_dyn[];
+    __shared__ uint32_t s_crc[1024];
+    __shared__ uint32_t s_scr[128];
+    __shared__ float2 s_lut[LUT_SIZE];
+    __shared__ float2 s_pre[PRE_ROWS * SYM_LEN];
+    __shared__ float2 s_tw[64];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float amp = P.amp;
+    for (int i = tid; i < 127; i += 64 * TX_WAVES) s_scr[i] = T.scr_word[i];
+    for (int i = tid; i < 1024; i += 64 * TX_WAVES) s_crc[i] = T.crc_tab[i];
+    for (int i = tid; i < LUT_SIZE; i += 64 * TX_WAVES) s_lut[i] = T.lut[i];
+    for (int i = tid; i < PRE_ROWS * SYM_LEN; i += 64 * TX_WAVES) {
+        float2 v = T.preamble[i];
+        s_pre[i] = make_float2(v.x * amp, v.y * amp);
+    }
+    for (int i = tid; i < 64; i += 64 * TX_WAVES) s_tw[i] = T.tw64[((i & 7) * (i >> 3)) & 63];
+    __syncthreads();
+
+    uint32_t *A = s_dyn + (size_t)wave * (a_words + TX_B_WORDS);
+    uint32_t *U = A + a_words;
+    float2 *buf = reinterpret_cast<float2 *>(U);
+
+    const int l = lane & 7, g = lane >> 3;
+    const float scale = 0.125f * amp;
+    uint32_t kinds = 0;
+    int d0 = -1;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int c = bin_code(8 * l + i);
+        if (c >= 0 && d0 < 0) d0 = c;
+        kinds |= (uint32_t)(c >= 0 ? 1 : (c == -1 ? 0 : (c == -2 ? 2 : 3))) << (2 * i);
+    }
+    uint64_t pneg_lo = T.pilot_neg[0] | ((uint64_t)T.pilot_neg[1] << 32);
+    uint64_t pneg_hi = T.pilot_neg[2] | ((uint64_t)T.pilot_neg[3] << 32);
+    asm volatile("" : "+s"(pneg_lo), "+s"(pneg_hi));
+
+    const uint32_t pre_rows = (P.flags & OFDMTX_F_PREAMBLE) ? PRE_ROWS : 0;
+    const uint32_t gap_rows = (P.flags & OFDMTX_F_ZEROGAP) ? GAP_ROWS : 0;
+    const bool swap_iq = (P.flags & OFDMTX_F_SWAPIQ) != 0;
+
+    for (uint32_t p = blockIdx.x * TX_WAVES + wave; p < P.n_pkts; p += gridDim.x * TX_WAVES) {
+        const Pkt k = load_pkt<UNIFORM>(P, p);
+        const RegimeInfo ri = regime_info((int)k.regime);
+        encode_packet(k, ri, T, payloads, A, U, s_crc, s_scr, lane, nullptr, nullptr, nullptr);
+
+        const uint32_t n_rows = pre_rows + 1u + k.n_sym + gap_rows;
+        const size_t row0 = UNIFORM ? (size_t)p * P.rows_per_pkt : (size_t)P.row_start[p];
+        float4 *out = reinterpret_cast<float4 *>(iq + row0 * SYM_LEN);
+        for (uint32_t r0 = 0; r0 < n_rows; r0 += 8u) {
+            const uint32_t r = r0 + g;
+            const int type = r >= n_rows ? 3 : (r < pre_rows ? 0 : (r - pre_rows <= k.n_sym ? 1 : 2));
+            uint64_t W = 0;
+            uint32_t nb = 1, lut_off = 0;
+            float pil = 1.f;
+            if (type == 1) {
+                const uint32_t s = r - pre_rows;                         // symbol index, 0 = SIGNAL
+                nb = s == 0 ? 1u : (uint32_t)ri.n_bpsc;                  // ftw/ftw_ofdm_mapper.cc:184-191
+                lut_off = s == 0 ? 0u : (uint32_t)ri.lut_off;
+                // message bit m sits at bit 16 + m of the word stream A[] (A[0] holds 16 spare bits)
+                const uint32_t bit = 16u + (s == 0 ? 0u : 48u + (s - 1u) * ri.n_cbps) + (uint32_t)d0 * nb;
+                const uint32_t w = bit >> 5, sh = bit & 31u;
+                const uint32_t b0 = A[w], b1 = A[w + 1], b2 = A[w + 2];
+                W = ((uint64_t)__funnelshift_l(b1, b0, sh) << 32) | __funnelshift_l(b2, b1, sh);
+                const uint32_t pidx = (k.pilot_base + s) % 127u;         // ftw/ftw_ofdm_pilot_cc.cc:116
+                pil = ((uint32_t)((pidx < 64u ? pneg_lo : pneg_hi) >> (pidx & 63u)) & 1u) ? -1.f : 1.f;
+            }
+            modulate_group(type, r, W, nb, lut_off, pil, 0u, nullptr, kinds, d0, l, g, lane, buf, s_lut, s_pre,
+                           s_tw, scale, swap_iq, out + (size_t)r0 * (SYM_LEN / 2),
+                           n_rows - r0 < 8u ? n_rows - r0 : 8u);
+            wave_sync();
+        }
+    }
 }
 
 }  // namespace
@@ -855,6 +953,7 @@ struct ofdmtx_plan {
     uint32_t *d_row_start;
     uint32_t *d_group_pkt;
     ofdmtx_pkt_info uni;   // uniform geometry
+    uint32_t tx_a_words;   // LDS words per wave the fused kernel needs for the largest packet
 };
 
 extern "C" {
@@ -993,6 +1092,16 @@ int ofdmtx_set_constellation(ofdmtx_ctx *c, int n_bpsc, const float *re_im, int 
 
 static inline uint32_t align16(uint32_t v) { return (v + 15u) & ~15u; }
 
+// LDS words k_tx needs per wave for a packet: natural MPDU (2 + n_words + 1) or message words
+// (2 SIGNAL + DATA + 3 spare), whichever is larger, rounded to 16 bytes
+static inline uint32_t tx_words_for(const ofdmtx_pkt_info &pi)
+{
+    uint32_t d = (uint32_t)(pi.plcp_len + 3) / 4 + 4;
+    uint32_t m = 2 + (uint32_t)(pi.n_sym * pi.n_cbps + 31) / 32 + 3;
+    uint32_t w = d > m ? d : m;
+    return (w + 3u) & ~3u;
+}
+
 static void plan_common(ofdmtx_plan *pl, ofdmtx_ctx *ctx, uint64_t n, int pilot_mode,
                         uint32_t pilot_start, unsigned flags, float amp)
 {
@@ -1039,6 +1148,7 @@ int ofdmtx_plan_uniform(ofdmtx_ctx *ctx, uint64_t n_pkts, int regime, uint32_t p
     pp.rows_per_pkt = (uint32_t)pi.n_rows;
     pp.total_rows = (uint32_t)(n_pkts * (uint64_t)pi.n_rows);
     pl->uni = pi;
+    pl->tx_a_words = tx_words_for(pi);
     ofdmtx_plan_sizes &sz = pl->sizes;
     sz.n_pkts = n_pkts;
     sz.payload_bytes = n_pkts ? (n_pkts - 1) * payload_stride + payload_len : 0;
@@ -1066,6 +1176,7 @@ int ofdmtx_plan_ragged(ofdmtx_ctx *ctx, uint64_t n_pkts, const uint8_t *regimes,
     plan_common(pl, ctx, n_pkts, pilot_mode, pilot_start, flags, amp);
     PlanParams &pp = pl->pp;
     pp.uniform = 0;
+    pl->tx_a_words = 16;
     pl->recs.resize(n_pkts);
     pl->row_start.resize(n_pkts + 1);
     pl->plcp_len.resize(n_pkts);
@@ -1081,6 +1192,7 @@ int ofdmtx_plan_ragged(ofdmtx_ctx *ctx, uint64_t n_pkts, const uint8_t *regimes,
             delete pl;
             return rc;
         }
+        if (tx_words_for(pi) > pl->tx_a_words) pl->tx_a_words = tx_words_for(pi);
         PktRec &r = pl->recs[i];
         memset(&r, 0, sizeof(r));
         r.pay_off = payload_off ? payload_off[i] : pay;
@@ -1255,10 +1367,22 @@ int ofdmtx_modulate(ofdmtx_ctx *ctx, const ofdmtx_plan *pl, const uint8_t *d_msg
 int ofdmtx_tx(ofdmtx_ctx *ctx, const ofdmtx_plan *pl, const uint8_t *d_payloads, uint8_t *d_work,
               float *d_iq, void *stream)
 {
-    if (!d_work) return OFDMTX_EINVAL;
-    int rc = ofdmtx_encode_bits(ctx, pl, d_payloads, nullptr, nullptr, nullptr, d_work, stream);
-    if (rc) return rc;
-    return ofdmtx_modulate(ctx, pl, d_work, nullptr, d_iq, stream);
+    (void)d_work;   // the fused kernel keeps the mapper messages in LDS
+    if (!ctx || !pl || pl->ctx != ctx || !d_iq) return OFDMTX_EINVAL;
+    if (!d_payloads && pl->sizes.payload_bytes) return OFDMTX_EINVAL;
+    if (pl->pp.n_pkts == 0) return OFDMTX_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int grid = grid_for(ctx, pl->pp.n_pkts, TX_WAVES, 8);
+    const size_t lds = (size_t)TX_WAVES * (pl->tx_a_words + TX_B_WORDS) * sizeof(uint32_t);
+    hipStream_t st = (hipStream_t)stream;
+    if (pl->pp.uniform)
+        hipLaunchKernelGGL(k_tx<true>, dim3(grid), dim3(64 * TX_WAVES), lds, st, pl->pp, ctx->tables(),
+                           d_payloads, reinterpret_cast<float2 *>(d_iq), pl->tx_a_words);
+    else
+        hipLaunchKernelGGL(k_tx<false>, dim3(grid), dim3(64 * TX_WAVES), lds, st, pl->pp, ctx->tables(),
+                           d_payloads, reinterpret_cast<float2 *>(d_iq), pl->tx_a_words);
+    HIPCHK(hipGetLastError());
+    return OFDMTX_OK;
 }
 
 }  // extern "C"
