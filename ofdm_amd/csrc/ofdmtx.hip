@@ -518,33 +518,35 @@ k_encode_bits(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads,
 // Symbol-level kernel
 // ======================================================================================
 
-__device__ inline float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ inline float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ inline float2 cmul(float2 a, float2 b)
+// Complex samples are handled as 2-float vectors so that hipcc emits packed VALU operations
+// (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: two floats per instruction).
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ inline v2f rot90(v2f a) { return (v2f){-a.y, a.x}; }          // * (+j)
+__device__ inline v2f cmul(v2f a, v2f b)                                  // a * b
 {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+    return __builtin_elementwise_fma((v2f){a.y, a.y}, rot90(b), (v2f){a.x, a.x} * b);
 }
-__device__ inline float2 mul_i(float2 a) { return make_float2(-a.y, a.x); }   // * (+j)
 
 // y[p] = sum_m x[m] e^{+j 2 pi m p / 8}, in place
-__device__ inline void idft8(float2 (&x)[8])
+__device__ inline void idft8(v2f (&x)[8])
 {
-    const float h = 0.70710678118654752440f;
-    float2 a0 = cadd(x[0], x[4]), a1 = csub(x[0], x[4]);
-    float2 a2 = cadd(x[2], x[6]), a3 = csub(x[2], x[6]);
-    float2 a4 = cadd(x[1], x[5]), a5 = csub(x[1], x[5]);
-    float2 a6 = cadd(x[3], x[7]), a7 = csub(x[3], x[7]);
-    float2 b0 = cadd(a0, a2), b2 = csub(a0, a2);
-    float2 b1 = cadd(a1, mul_i(a3)), b3 = csub(a1, mul_i(a3));
-    float2 b4 = cadd(a4, a6), b6 = csub(a4, a6);
-    float2 b5 = cadd(a5, mul_i(a7)), b7 = csub(a5, mul_i(a7));
-    float2 w5 = make_float2(h * (b5.x - b5.y), h * (b5.x + b5.y));      // b5 * e^{+j pi/4}
-    float2 w7 = make_float2(-h * (b7.x + b7.y), h * (b7.x - b7.y));     // b7 * e^{+j 3pi/4}
-    float2 w6 = mul_i(b6);
-    x[0] = cadd(b0, b4); x[4] = csub(b0, b4);
-    x[1] = cadd(b1, w5); x[5] = csub(b1, w5);
-    x[2] = cadd(b2, w6); x[6] = csub(b2, w6);
-    x[3] = cadd(b3, w7); x[7] = csub(b3, w7);
+    const v2f h = {0.70710678118654752440f, 0.70710678118654752440f};
+    const v2f a0 = x[0] + x[4], a1 = x[0] - x[4];
+    const v2f a2 = x[2] + x[6], a3 = x[2] - x[6];
+    const v2f a4 = x[1] + x[5], a5 = x[1] - x[5];
+    const v2f a6 = x[3] + x[7], a7 = x[3] - x[7];
+    const v2f b0 = a0 + a2, b2 = a0 - a2;
+    const v2f b1 = a1 + rot90(a3), b3 = a1 - rot90(a3);
+    const v2f b4 = a4 + a6, b6 = a4 - a6;
+    const v2f b5 = a5 + rot90(a7), b7 = a5 - rot90(a7);
+    const v2f t5 = b5 + rot90(b5);                 // b5 * e^{+j pi/4}  = h * t5
+    const v2f t7 = rot90(b7) - b7;                 // b7 * e^{+j 3pi/4} = h * t7
+    const v2f w6 = rot90(b6);
+    x[0] = b0 + b4; x[4] = b0 - b4;
+    x[1] = __builtin_elementwise_fma(h, t5, b1); x[5] = __builtin_elementwise_fma(-h, t5, b1);
+    x[2] = b2 + w6; x[6] = b2 - w6;
+    x[3] = __builtin_elementwise_fma(h, t7, b3); x[7] = __builtin_elementwise_fma(-h, t7, b3);
 }
 
 // What FFT bin k carries: ftw/ftw_ofdm_pilot_cc.cc:119-155 then ftw/ftw_ofdm_cmap_cc.cc:102-107.
@@ -570,85 +572,90 @@ constexpr int RS = 88;   // float2 per row in the staging layout
 //   buf   the wave's LDS area of 8*RS float2; dst = first of the group's `rows_here` rows
 __device__ inline void modulate_group(int type, uint32_t pre_row, uint64_t W, uint32_t nb, uint32_t lut_off,
                                       float pil, uint32_t map_row, float2 *__restrict__ mapped,
-                                      uint32_t kinds, int d0, int l, int g, int lane, float2 *buf,
-                                      const float2 *s_lut, const float2 *s_pre, const float2 *s_tw,
-                                      float scale, bool swap_iq, float4 *__restrict__ dst, uint32_t rows_here)
+                                      uint32_t kinds, int d0, int l, int g, int lane, float2 *buf_,
+                                      const float2 *s_lut_, const float2 *s_pre_, const float2 *s_tw_,
+                                      bool swap_iq, float4 *__restrict__ dst, uint32_t rows_here)
 {
-    // ---- mapper + pilots + carrier map, bins in natural order (transposition layout)
-    if (type == 1) {
-        uint32_t used = 0, nd = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            float2 v;
-            const uint32_t kind = (kinds >> (2 * i)) & 3u;
-            if (kind == 1u) {
-                const uint32_t idx = (uint32_t)((W << used) >> (64u - nb));
-                v = s_lut[lut_off + idx];
-                if (mapped) mapped[(size_t)map_row * 48u + d0 + nd] = v;
-                used += nb;
-                nd++;
-            } else if (kind == 0u) {
-                v = make_float2(0.f, 0.f);
-            } else {
-                v = make_float2(kind == 2u ? pil : -pil, 0.f);
-            }
-            buf[g * TG + 9 * l + i] = v;
-        }
-    }
-    wave_sync();
+    v2f *buf = reinterpret_cast<v2f *>(buf_);
+    const v2f *s_lut = reinterpret_cast<const v2f *>(s_lut_);
+    const v2f *s_pre = reinterpret_cast<const v2f *>(s_pre_);
+    const v2f *s_tw = reinterpret_cast<const v2f *>(s_tw_);
+    const bool any_symbol = __ballot(type == 1) != 0ull;
+    v2f x[8];
 
-    // ---- 64-point inverse DFT as 8 x 8: x[8q+p] = sum_l W8^{lq} W64^{lp} sum_m X[l+8m] W8^{mp}
-    float2 x[8];
-    if (type == 1) {
+    if (any_symbol) {
+        // ---- mapper + pilots + carrier map, bins in natural order (transposition layout).
+        // Branch-free per bin: every bin looks up the LUT with the bits at the running offset;
+        // only data bins advance the offset, the others replace the value.
+        if (type == 1) {
+            uint32_t used = 0, nd = 0;
 #pragma unroll
-        for (int m = 0; m < 8; m++) x[m] = buf[g * TG + l + 9 * m];
+            for (int i = 0; i < 8; i++) {
+                const uint32_t kind = (kinds >> (2 * i)) & 3u;
+                const uint32_t idx = (uint32_t)((W << used) >> (64u - nb));
+                v2f v = s_lut[lut_off + idx];
+                if (mapped && kind == 1u) mapped[(size_t)map_row * 48u + d0 + nd] = make_float2(v.x, v.y);
+                const bool data = kind == 1u;
+                const float pv = kind == 2u ? pil : (kind == 3u ? -pil : 0.f);
+                v.x = data ? v.x : pv;
+                v.y = data ? v.y : 0.f;
+                used += data ? nb : 0u;
+                nd += data ? 1u : 0u;
+                buf[g * TG + 9 * l + i] = v;
+            }
+        }
+        wave_sync();
+
+        // ---- 64-point inverse DFT as 8 x 8: x[8q+p] = sum_l W8^{lq} W64^{lp} sum_m X[l+8m] W8^{mp}
+        // (s_tw holds W64^{lp} times the output scale, so no separate scaling pass is needed)
+        if (type == 1) {
+#pragma unroll
+            for (int m = 0; m < 8; m++) x[m] = buf[g * TG + l + 9 * m];
+        }
+        wave_sync();
+        if (type == 1) {
+            idft8(x);
+#pragma unroll
+            for (int p = 0; p < 8; p++) x[p] = cmul(x[p], s_tw[8 * p + l]);
+#pragma unroll
+            for (int p = 0; p < 8; p++) buf[g * TG + 9 * p + l] = x[p];
+        }
+        wave_sync();
+        if (type == 1) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) x[i] = buf[g * TG + 9 * l + i];   // lane now plays p = l
+        }
+        wave_sync();
     }
-    wave_sync();
-    if (type == 1) {
-        idft8(x);
-#pragma unroll
-        for (int p = 1; p < 8; p++) x[p] = cmul(x[p], s_tw[8 * p + l]);
-#pragma unroll
-        for (int p = 0; p < 8; p++) buf[g * TG + 9 * p + l] = x[p];
-    }
-    wave_sync();
-    if (type == 1) {
-#pragma unroll
-        for (int i = 0; i < 8; i++) x[i] = buf[g * TG + 9 * l + i];   // lane now plays p = l
-    }
-    wave_sync();
 
     // ---- the row's 80 samples into the staging area.  Lane l owns samples l + 8i, i = 0..9:
     // symbol rows: out[o] = x[(o + 48) % 64] (cyclic prefix, examples/ftw_ofdm.py:121-123), so
     // i = 0,1 repeat q = 6,7 and i >= 2 is q = i - 2; preamble rows copy the table, gap rows are 0.
-    float2 o10[10];
+    v2f o10[10];
     if (type == 1) {
         idft8(x);                                                     // x[q] = sample 8q + l
-#pragma unroll
-        for (int q = 0; q < 8; q++) x[q] = make_float2(x[q].x * scale, x[q].y * scale);
         o10[0] = x[6];
         o10[1] = x[7];
 #pragma unroll
         for (int q = 0; q < 8; q++) o10[q + 2] = x[q];
     } else if (type == 0) {
-        const uint32_t r = pre_row;
 #pragma unroll
-        for (int i = 0; i < 10; i++) o10[i] = s_pre[r * SYM_LEN + l + 8 * i];
+        for (int i = 0; i < 10; i++) o10[i] = s_pre[pre_row * SYM_LEN + l + 8 * i];
     } else {
 #pragma unroll
-        for (int i = 0; i < 10; i++) o10[i] = make_float2(0.f, 0.f);
+        for (int i = 0; i < 10; i++) o10[i] = (v2f){0.f, 0.f};
     }
     if (swap_iq) {                                                    // examples/ftw_ofdm.py:155-163
 #pragma unroll
-        for (int i = 0; i < 10; i++) o10[i] = make_float2(o10[i].y, o10[i].x);
+        for (int i = 0; i < 10; i++) o10[i] = (v2f){o10[i].y, o10[i].x};
     }
 #pragma unroll
     for (int i = 0; i < 10; i++) buf[g * RS + l + 8 * i] = o10[i];
     wave_sync();
 
     // ---- 8 rows = 5120 contiguous bytes, 16 B per lane per store: always five store
-    // instructions per iteration (WAIT_WINDOW counts them); lanes beyond the end of the
-    // stream are masked, which happens in the last group only
+    // instructions per full group (k_modulate's counted wait relies on that); lanes beyond the
+    // end of the stream are masked, which happens in a last, partial group only
     if (rows_here == 8u) {
 #pragma unroll
         for (int i = 0; i < 5; i++) {
@@ -663,7 +670,6 @@ __device__ inline void modulate_group(int type, uint32_t pre_row, uint64_t W, ui
                 dst[e] = *reinterpret_cast<const float4 *>(buf + (e / 40) * RS + (e % 40) * 2);
         }
     }
-
 }
 
 constexpr int MOD_WAVES = 4;
@@ -733,6 +739,8 @@ k_modulate(PlanParams P, DevTables T, const uint8_t *__restrict__ msg, float2 *_
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float amp = P.amp;
+    // 1/sqrt(64) (examples/ftw_ofdm.py:126) is a power of two: (x*0.125)*amp == x*(0.125*amp)
+    const float scale = 0.125f * amp;
     for (int i = tid; i < LUT_SIZE; i += 64 * MOD_WAVES) s_lut[i] = T.lut[i];
     for (int i = tid; i < PRE_ROWS * SYM_LEN; i += 64 * MOD_WAVES) {
         float2 v = T.preamble[i];                         // pu:508 literals as float32 ...
@@ -740,12 +748,14 @@ k_modulate(PlanParams P, DevTables T, const uint8_t *__restrict__ msg, float2 *_
     }
     // twiddles W64^{l*p} of the 8x8 decomposition, entry 8*p + l (lanes of a symbol read 8
     // consecutive entries, the 8 symbols of a wave read the same ones)
-    for (int i = tid; i < 64; i += 64 * MOD_WAVES) s_tw[i] = T.tw64[((i & 7) * (i >> 3)) & 63];
+    for (int i = tid; i < 64; i += 64 * MOD_WAVES) {
+        const float2 w = T.tw64[((i & 7) * (i >> 3)) & 63];
+        s_tw[i] = make_float2(w.x * scale, w.y * scale);
+    }
     __syncthreads();
 
     const int l = lane & 7, g = lane >> 3;
     float2 *buf = s_buf[wave];
-    const float scale = 0.125f * amp;   // 1/sqrt(64) is a power of two: (x*0.125)*amp == x*(0.125*amp)
 
     // the lane's own eight consecutive bins 8l..8l+7 (mapping stage)
     // kinds: 2 bits per bin -- 0 null, 1 data, 2 pilot +p, 3 pilot -p; d0 = first data carrier
@@ -801,7 +811,7 @@ k_modulate(PlanParams P, DevTables T, const uint8_t *__restrict__ msg, float2 *_
 
         modulate_group(type, cw_c >> 18, W_c, (cw_c >> 2) & 7u, (cw_c >> 10) & 127u,
                        (cw_c >> 17) & 1u ? -1.f : 1.f, map_c, mapped, kinds, d0, l, g, lane, buf, s_lut, s_pre,
-                       s_tw, scale, swap_iq, reinterpret_cast<float4 *>(iq + (size_t)grp * 8u * SYM_LEN),
+                       s_tw, swap_iq, reinterpret_cast<float4 *>(iq + (size_t)grp * 8u * SYM_LEN),
                        P.total_rows - grp * 8u < 8u ? P.total_rows - grp * 8u : 8u);
 
         // ---- rotate the pipeline: retire the window of the next group, request the one after
@@ -846,6 +856,8 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads, float2 *__
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float amp = P.amp;
+    // 1/sqrt(64) (examples/ftw_ofdm.py:126) is a power of two: (x*0.125)*amp == x*(0.125*amp)
+    const float scale = 0.125f * amp;
     for (int i = tid; i < 127; i += 64 * TX_WAVES) s_scr[i] = T.scr_word[i];
     for (int i = tid; i < 1024; i += 64 * TX_WAVES) s_crc[i] = T.crc_tab[i];
     for (int i = tid; i < LUT_SIZE; i += 64 * TX_WAVES) s_lut[i] = T.lut[i];
@@ -853,7 +865,10 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads, float2 *__
         float2 v = T.preamble[i];
         s_pre[i] = make_float2(v.x * amp, v.y * amp);
     }
-    for (int i = tid; i < 64; i += 64 * TX_WAVES) s_tw[i] = T.tw64[((i & 7) * (i >> 3)) & 63];
+    for (int i = tid; i < 64; i += 64 * TX_WAVES) {
+        const float2 w = T.tw64[((i & 7) * (i >> 3)) & 63];
+        s_tw[i] = make_float2(w.x * scale, w.y * scale);
+    }
     __syncthreads();
 
     uint32_t *A = s_dyn + (size_t)wave * (a_words + TX_B_WORDS);
@@ -861,7 +876,6 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads, float2 *__
     float2 *buf = reinterpret_cast<float2 *>(U);
 
     const int l = lane & 7, g = lane >> 3;
-    const float scale = 0.125f * amp;
     uint32_t kinds = 0;
     int d0 = -1;
 #pragma unroll
@@ -905,7 +919,7 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads, float2 *__
                 pil = ((uint32_t)((pidx < 64u ? pneg_lo : pneg_hi) >> (pidx & 63u)) & 1u) ? -1.f : 1.f;
             }
             modulate_group(type, r, W, nb, lut_off, pil, 0u, nullptr, kinds, d0, l, g, lane, buf, s_lut, s_pre,
-                           s_tw, scale, swap_iq, out + (size_t)r0 * (SYM_LEN / 2),
+                           s_tw, swap_iq, out + (size_t)r0 * (SYM_LEN / 2),
                            n_rows - r0 < 8u ? n_rows - r0 : 8u);
             wave_sync();
         }
