@@ -18,10 +18,18 @@
 #include <string.h>
 
 #include <new>
+#include <utility>
 #include <vector>
 
 #include "ofdm_tables.h"
 #include "ofdmtx.h"
+
+// Section markers in the generated assembly (tools/asm_sections.py); no code is emitted.
+#ifdef OFDMTX_ASM_MARKERS
+#define SEC(name) asm volatile("; SEC " name)
+#else
+#define SEC(name) do { } while (0)
+#endif
 
 namespace {
 
@@ -48,7 +56,7 @@ struct RegimeInfo {
 };
 
 // pu:39-78 (modulation / rate), pu:81 (N_dbps), pu:129-144 (RATE nibble)
-__host__ __device__ inline RegimeInfo regime_info(int regime)
+__host__ __device__ __forceinline__ RegimeInfo regime_info(int regime)
 {
     switch (regime) {
     case 1: return {48, 1, 24, 0x0D, 0, 2};
@@ -111,7 +119,7 @@ struct Pkt {
 };
 
 template <bool UNIFORM>
-__device__ inline Pkt load_pkt(const PlanParams &P, uint32_t p)
+__device__ __forceinline__ Pkt load_pkt(const PlanParams &P, uint32_t p)
 {
     Pkt k;
     if (UNIFORM) {
@@ -146,7 +154,7 @@ __device__ inline Pkt load_pkt(const PlanParams &P, uint32_t p)
 // from moving LDS accesses across this point ("memory" clobber) and (b) at most a wait for the
 // wave's own LDS operations.  Deliberately NOT a fence: a release fence also drains the
 // vector-memory counter, i.e. it would wait for every global store still in flight.
-__device__ inline void wave_sync()
+__device__ __forceinline__ void wave_sync()
 {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
@@ -173,7 +181,7 @@ __device__ inline void wave_sync()
 constexpr uint32_t CRC_POLY = 0xEDB88320u;   // ftw/ftw_crc32.cc:45
 
 // a(x) * b(x) mod P(x) in the reflected representation (x^0 = bit 31)
-__device__ inline uint32_t crc_mulmod(uint32_t a, uint32_t b)
+__device__ __forceinline__ uint32_t crc_mulmod(uint32_t a, uint32_t b)
 {
     uint32_t p = 0;
 #pragma unroll 4
@@ -187,7 +195,7 @@ __device__ inline uint32_t crc_mulmod(uint32_t a, uint32_t b)
 
 // Coded bit with absolute index P (0 = first SIGNAL coded bit) from the scrambled stream
 // held as MSB-first 32-bit words: pu:287-307, g0 = 133o -> even index, g1 = 171o -> odd.
-__device__ inline uint32_t coded_bit(const uint32_t *U, uint32_t P)
+__device__ __forceinline__ uint32_t coded_bit(const uint32_t *U, uint32_t P)
 {
     uint32_t n = P >> 1;
     uint32_t w = n >> 5;
@@ -197,129 +205,109 @@ __device__ inline uint32_t coded_bit(const uint32_t *U, uint32_t P)
     return __popc(win & ((P & 1u) ? 0x4Fu : 0x6Du)) & 1u;
 }
 
-// bits [off, off+len) of an MSB-first word array, right-aligned (off/len constant after unrolling)
-template <int NX>
-__device__ inline uint32_t getbits(const uint32_t (&X)[NX], int off, int len)
-{
-    const int w = off >> 5, o = off & 31;
-    const uint32_t mask = (1u << len) - 1u;
-    if (o + len <= 32) return (X[w] >> (32 - o - len)) & mask;
-    return ((X[w] << (o + len - 32)) | (X[w + 1] >> (64 - o - len))) & mask;
-}
-
-template <int NW>
-__device__ inline void putbits(uint32_t (&W)[NW], int off, int len, uint32_t v)
-{
-    const int w = off >> 5, o = off & 31;
-    if (o + len <= 32) {
-        W[w] |= v << (32 - o - len);
-    } else {
-        W[w] |= v >> (o + len - 32);
-        W[w + 1] |= v << (64 - o - len);
-    }
-}
-
-__device__ inline uint32_t spread8(uint32_t x)      // bit k -> bit 2k, 8 bits
-{
-    x = (x | (x << 4)) & 0x0F0Fu;
-    x = (x | (x << 2)) & 0x3333u;
-    x = (x | (x << 1)) & 0x5555u;
-    return x;
-}
-__device__ inline uint32_t spread16(uint32_t x)     // bit k -> bit 2k, 16 bits
-{
-    x = (x | (x << 8)) & 0x00FF00FFu;
-    x = (x | (x << 4)) & 0x0F0F0F0Fu;
-    x = (x | (x << 2)) & 0x33333333u;
-    x = (x | (x << 1)) & 0x55555555u;
-    return x;
-}
-__device__ inline uint32_t spread3to4(uint32_t x)   // 4 groups of 3 bits -> top 3 bits of 4 nibbles
-{
-    return ((x & 0xE00u) << 4) | ((x & 0x1C0u) << 3) | ((x & 0x038u) << 2) | ((x & 0x007u) << 1);
-}
-__device__ inline uint32_t compress3of4(uint32_t x) // keep the top 3 bits of each of 8 nibbles -> 24 bits
-{
-    uint32_t t = (x >> 1) & 0x77777777u;
-    t = (t & 0x07070707u) | ((t & 0x70707070u) >> 1);
-    t = (t & 0x003F003Fu) | ((t & 0x3F003F00u) >> 2);
-    return (t & 0x00000FFFu) | ((t & 0x0FFF0000u) >> 4);
-}
-
-// Encoder + puncturing of one piece.  V holds INB+6 consecutive scrambled bits, oldest first
-// (the first six are the encoder's history); returns OUTB punctured coded bits, first bit in
-// the MSB of the field.  Generators pu:287-307; puncturing patterns pu:316-341:
-//   rate 1/2: A0 B0 A1 B1 ...          8 in -> 16 out
-//   rate 3/4: A0 B0 A1 B2 per 3 in    12 in -> 16 out   (coded index mod 6 in {0,1,2,5})
-//   rate 2/3: A0 B0 A1 per 2 in       16 in -> 24 out   (coded index mod 4 in {0,1,2})
-template <int PUNCT> struct Piece;
-template <> struct Piece<0> { static constexpr int INB = 8, OUTB = 16; };
-template <> struct Piece<1> { static constexpr int INB = 12, OUTB = 16; };
-template <> struct Piece<2> { static constexpr int INB = 16, OUTB = 24; };
-
+// Index into the coded stream (relative to the symbol's first coded bit) of punctured index
+// q (relative to the symbol's first punctured bit): pu:309-341.  Symbols hold whole
+// puncturing periods, so the relation is the same in every symbol.
 template <int PUNCT>
-__device__ inline uint32_t encode_piece(uint32_t V)
+__device__ constexpr int unpuncture(int q)
 {
-    constexpr uint32_t mask = (1u << Piece<PUNCT>::INB) - 1u;
-    const uint32_t A = (V ^ (V >> 2) ^ (V >> 3) ^ (V >> 5) ^ (V >> 6)) & mask;   // 133 octal
-    const uint32_t B = (V ^ (V >> 1) ^ (V >> 2) ^ (V >> 3) ^ (V >> 6)) & mask;   // 171 octal
-    if (PUNCT == 0) return (spread8(A) << 1) | spread8(B);
-    if (PUNCT == 1) {
-        const uint32_t Ae = spread3to4(A), Be = spread3to4(B);
-        return (Ae & 0x8888u) | (((Be & 0xAAAAu) | (Ae & 0x4444u)) >> 1);
-    }
-    return compress3of4((spread16(A) << 1) | spread16(B));
+    return PUNCT == 1 ? 6 * (q / 4) + ((q % 4) == 3 ? 5 : (q % 4))      // keep coded index mod 6 in {0,1,2,5}
+         : PUNCT == 2 ? 4 * (q / 3) + q % 3                                // keep coded index mod 4 in {0,1,2}
+                      : q;
+}
+
+// One bit of the per-symbol bit table, with every index a compile-time constant (a plain
+// unrolled loop leaves hipcc free to keep the loop and index the register arrays through
+// scratch memory): dst bit J <- coded bit unpuncture(Q), i.e. bit n of stream A (even) or B (odd).
+template <int PUNCT, int J, int Q, int NA, int NW>
+__device__ __forceinline__ void move_coded_bit(const uint32_t (&Aw)[NA], const uint32_t (&Bw)[NA],
+                                               uint32_t (&dst)[NW])
+{
+    constexpr int p = unpuncture<PUNCT>(Q), n = p >> 1;
+    const uint32_t w = (p & 1) ? Bw[n >> 5] : Aw[n >> 5];
+    dst[J >> 5] |= ((w >> (31 - (n & 31))) & 1u) << (31 - (J & 31));
+}
+
+// punctured index feeding interleaved position J of a symbol: k = 16r + c with J = R*c + u,
+// r = S*(u/S) + ((u%S + c) % S)  (inverse of pu:241-253 followed by pu:267-273)
+template <int NBPSC>
+__device__ constexpr int deinterleave(int j)
+{
+    constexpr int R = 3 * NBPSC, S = NBPSC / 2 > 1 ? NBPSC / 2 : 1;
+    const int c = j / R, u = j % R;
+    return 16 * (S * (u / S) + ((u % S) + c) % S) + c;
+}
+
+template <int NBPSC, int PUNCT, int NA, int NW, int... J>
+__device__ __forceinline__ void interleave_bits(const uint32_t (&Aw)[NA], const uint32_t (&Bw)[NA],
+                                                uint32_t (&out)[NW], std::integer_sequence<int, J...>)
+{
+    (move_coded_bit<PUNCT, J, deinterleave<NBPSC>(J)>(Aw, Bw, out), ...);
+}
+
+template <int PUNCT, int NA, int NW, int... Q>
+__device__ __forceinline__ void punctured_bits(const uint32_t (&Aw)[NA], const uint32_t (&Bw)[NA],
+                                               uint32_t (&out)[NW], std::integer_sequence<int, Q...>)
+{
+    (move_coded_bit<PUNCT, Q, Q>(Aw, Bw, out), ...);
 }
 
 // DATA symbols of one packet, one lane per symbol.  OUTW: MSB-first words, word 2 holds the
 // first 32 interleaved DATA bits (words 0,1 carry the SIGNAL symbol).
+//
+// The encoder outputs of a symbol are produced at full rate as two word streams
+//   A[n] = u[n]^u[n-2]^u[n-3]^u[n-5]^u[n-6]   (133 octal, pu:287-307)
+//   B[n] = u[n]^u[n-1]^u[n-2]^u[n-3]^u[n-6]   (171 octal)
+// with funnel shifts and 3-input XORs; puncturing (pu:309-341) and both interleaver
+// permutations (pu:231-277) then collapse into ONE compile-time table "output bit j comes from
+// bit n of A or of B", i.e. one bit-field extract and one shift-or per output bit.
 template <int NBPSC, int PUNCT>
-__device__ inline void encode_data_symbols(const uint32_t *U, uint32_t *OUTW, uint32_t n_sym,
+__device__ __forceinline__ void encode_data_symbols(const uint32_t *U, uint32_t *OUTW, uint32_t n_sym,
                                            uint8_t *cod_out, int lane)
 {
     constexpr int N = 48 * NBPSC;                                  // coded bits per symbol
     constexpr int NDBPS = PUNCT == 0 ? N / 2 : (PUNCT == 1 ? N * 3 / 4 : N * 2 / 3);
-    constexpr int R = 3 * NBPSC;                                   // N / 16
-    constexpr int S = NBPSC / 2 > 1 ? NBPSC / 2 : 1;
     constexpr int NW = (N + 31) / 32;
-    constexpr int NX = (NDBPS + 6 + 31) / 32 + 1;
-    constexpr int INB = Piece<PUNCT>::INB, OUTB = Piece<PUNCT>::OUTB;
-    static_assert(NDBPS % INB == 0, "symbol is a whole number of pieces");
+    constexpr int NA = (NDBPS + 31) / 32;                          // words of the A / B streams
+    constexpr int NX = NA + 1;                                     // scrambled bits incl. 6 bits of history
 
     for (uint32_t s = lane; s < n_sym; s += 64) {
-        // scrambled bits [24 + s*NDBPS - 6, 24 + (s+1)*NDBPS), left-aligned in X
+        // scrambled bits [24 + s*NDBPS - 6, ...), left-aligned in X
         const uint32_t b0 = 18u + s * NDBPS;
         const uint32_t w0 = b0 >> 5, o = b0 & 31u;
         uint32_t X[NX];
 #pragma unroll
-        for (int i = 0; i < NX - 1; i++) X[i] = __funnelshift_l(U[w0 + i + 1], U[w0 + i], o);
-        X[NX - 1] = 0;
+        for (int i = 0; i < NX; i++) X[i] = __funnelshift_l(U[w0 + i + 1], U[w0 + i], o);
 
-        uint32_t Pw[NW + 1];                                       // punctured coded bits of the symbol
+        // A/B bit t (t = 0 .. NDBPS-1) needs X bits t+6 (u[n]) down to t (u[n-6])
+        uint32_t Aw[NA], Bw[NA];
 #pragma unroll
-        for (int i = 0; i <= NW; i++) Pw[i] = 0;
-#pragma unroll
-        for (int p = 0; p < NDBPS / INB; p++)
-            putbits(Pw, p * OUTB, OUTB, encode_piece<PUNCT>(getbits(X, p * INB, INB + 6)));
+        for (int i = 0; i < NA; i++) {
+            const uint32_t y0 = X[i];
+            const uint32_t y1 = __funnelshift_l(X[i + 1], X[i], 1);
+            const uint32_t y3 = __funnelshift_l(X[i + 1], X[i], 3);
+            const uint32_t y4 = __funnelshift_l(X[i + 1], X[i], 4);
+            const uint32_t y5 = __funnelshift_l(X[i + 1], X[i], 5);
+            const uint32_t y6 = __funnelshift_l(X[i + 1], X[i], 6);
+            const uint32_t common = y6 ^ y3 ^ y0;                  // u[n] ^ u[n-3] ^ u[n-6]
+            Aw[i] = common ^ y4 ^ y1;                              // ^ u[n-2] ^ u[n-5]
+            Bw[i] = common ^ y5 ^ y4;                              // ^ u[n-1] ^ u[n-2]
+        }
 
-        if (cod_out) {
+        if (cod_out) {                                             // tap: punctured stream in order
+            uint32_t Pw[NW];
+#pragma unroll
+            for (int i = 0; i < NW; i++) Pw[i] = 0;
+            punctured_bits<PUNCT>(Aw, Bw, Pw, std::make_integer_sequence<int, N>{});
 #pragma unroll
             for (int t = 0; t < N / 8; t++)
                 cod_out[6u + s * (N / 8) + t] = (uint8_t)(Pw[t >> 2] >> (24 - 8 * (t & 3)));
         }
 
-        // interleaver: bit k = 16r + c of the symbol goes to j = R*c + S*(u/S) + ((r - c) mod S),
-        // u = r (pu:241-253 then pu:267-273); written here as a gather over j
         uint32_t out[NW];
 #pragma unroll
         for (int i = 0; i < NW; i++) out[i] = 0;
-#pragma unroll
-        for (int j = 0; j < N; j++) {
-            const int c = j / R, u = j % R;
-            const int r = S * (u / S) + ((u % S) + c) % S;
-            const int k = 16 * r + c;
-            out[j >> 5] |= ((Pw[k >> 5] >> (31 - (k & 31))) & 1u) << (31 - (j & 31));
-        }
+        interleave_bits<NBPSC, PUNCT>(Aw, Bw, out, std::make_integer_sequence<int, N>{});
 
         if (N % 32 == 0) {
 #pragma unroll
@@ -339,7 +327,7 @@ __device__ inline void encode_data_symbols(const uint32_t *U, uint32_t *OUTW, ui
 // words of LDS (first the natural-order MPDU, finally the message words OUTW: OUTW[0] low half
 // and OUTW[1] = the 48 SIGNAL bits, OUTW[2..] = interleaved DATA bits, all MSB first);
 // U: >= n_words + 2 words.  plcp_out / scr_out / cod_out are optional taps (global memory).
-__device__ inline void encode_packet(const Pkt &k, const RegimeInfo &ri, const DevTables &T,
+__device__ __forceinline__ void encode_packet(const Pkt &k, const RegimeInfo &ri, const DevTables &T,
                                      const uint8_t *__restrict__ payloads, uint32_t *A, uint32_t *U,
                                      const uint32_t *s_crc, const uint32_t *s_scr, int lane,
                                      uint8_t *plcp_out, uint8_t *scr_out, uint8_t *cod_out)
@@ -351,6 +339,7 @@ __device__ inline void encode_packet(const Pkt &k, const RegimeInfo &ri, const D
     const uint32_t n_words = (plcp_len + 3u) / 4u;                           // stream words
     const uint32_t n_dw = (mpdu_len + 3u) / 4u;                              // MPDU dwords
 
+    SEC("e1_stage");
     // ---- 1. MPDU in natural byte order (pu:28-36,100), Dw[-2], Dw[-1] and the tail zero
     uint32_t *Dw = A + 2;
     {
@@ -382,6 +371,7 @@ __device__ inline void encode_packet(const Pkt &k, const RegimeInfo &ri, const D
     }
     wave_sync();
 
+    SEC("e2_crc");
     // ---- 2. CRC-32 of the MPDU (ftw/ftw_crc32.cc:52-57)
     uint32_t fcs;
     {
@@ -406,6 +396,7 @@ __device__ inline void encode_packet(const Pkt &k, const RegimeInfo &ri, const D
         fcs = __brev(part) ^ 0xFFFFFFFFu;      // state bit-reversed, then ^~0 (ftw/ftw_crc32.cc:58-63,75)
     }
 
+    SEC("e3_words");
     // ---- 3. PLCP stream words (pu:128-205) and scrambler (pu:344-367)
     {
         const uint32_t rev = __brev(length) >> 20;                           // pu:147-150
@@ -433,6 +424,7 @@ __device__ inline void encode_packet(const Pkt &k, const RegimeInfo &ri, const D
     }
     wave_sync();
 
+    SEC("e4_signal");
     // ---- 4. SIGNAL symbol: 48 coded bits, N = 48 first permutation only (pu:245-249)
     uint32_t *OUTW = A;
     uint8_t *co = cod_out ? cod_out + k.msg_off : nullptr;
@@ -458,6 +450,7 @@ __device__ inline void encode_packet(const Pkt &k, const RegimeInfo &ri, const D
         }
     }
 
+    SEC("e5_data");
     // ---- 5. DATA symbols
     switch (k.regime) {
     case 1: encode_data_symbols<1, 0>(U, OUTW, k.n_sym, co, lane); break;
@@ -522,14 +515,14 @@ k_encode_bits(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads,
 // (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: two floats per instruction).
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-__device__ inline v2f rot90(v2f a) { return (v2f){-a.y, a.x}; }          // * (+j)
-__device__ inline v2f cmul(v2f a, v2f b)                                  // a * b
+__device__ __forceinline__ v2f rot90(v2f a) { return (v2f){-a.y, a.x}; }          // * (+j)
+__device__ __forceinline__ v2f cmul(v2f a, v2f b)                                  // a * b
 {
     return __builtin_elementwise_fma((v2f){a.y, a.y}, rot90(b), (v2f){a.x, a.x} * b);
 }
 
 // y[p] = sum_m x[m] e^{+j 2 pi m p / 8}, in place
-__device__ inline void idft8(v2f (&x)[8])
+__device__ __forceinline__ void idft8(v2f (&x)[8])
 {
     const v2f h = {0.70710678118654752440f, 0.70710678118654752440f};
     const v2f a0 = x[0] + x[4], a1 = x[0] - x[4];
@@ -551,7 +544,7 @@ __device__ inline void idft8(v2f (&x)[8])
 
 // What FFT bin k carries: ftw/ftw_ofdm_pilot_cc.cc:119-155 then ftw/ftw_ofdm_cmap_cc.cc:102-107.
 //   >= 0 : data carrier index 0..47;  -1 : null;  -2 : pilot with +p;  -3 : pilot with -p
-__device__ inline int bin_code(int k)
+__device__ __forceinline__ int bin_code(int k)
 {
     int f = k < 32 ? k : k - 64;
     if (f == 0 || f > 26 || f < -26) return -1;
@@ -570,7 +563,7 @@ constexpr int RS = 88;   // float2 per row in the staging layout
 //   W     the lane's 64 message bits, first wanted bit at bit 63 (bins 8l..8l+7, nb bits each)
 //   kinds 2 bits per bin: 0 null, 1 data, 2 pilot +p, 3 pilot -p; d0 = first data carrier of the lane
 //   buf   the wave's LDS area of 8*RS float2; dst = first of the group's `rows_here` rows
-__device__ inline void modulate_group(int type, uint32_t pre_row, uint64_t W, uint32_t nb, uint32_t lut_off,
+__device__ __forceinline__ void modulate_group(int type, uint32_t pre_row, uint64_t W, uint32_t nb, uint32_t lut_off,
                                       float pil, uint32_t map_row, float2 *__restrict__ mapped,
                                       uint32_t kinds, int d0, int l, int g, int lane, float2 *buf_,
                                       const float2 *s_lut_, const float2 *s_pre_, const float2 *s_tw_,
@@ -583,6 +576,7 @@ __device__ inline void modulate_group(int type, uint32_t pre_row, uint64_t W, ui
     const bool any_symbol = __ballot(type == 1) != 0ull;
     v2f x[8];
 
+    SEC("map");
     if (any_symbol) {
         // ---- mapper + pilots + carrier map, bins in natural order (transposition layout).
         // Branch-free per bin: every bin looks up the LUT with the bits at the running offset;
@@ -606,6 +600,7 @@ __device__ inline void modulate_group(int type, uint32_t pre_row, uint64_t W, ui
         }
         wave_sync();
 
+        SEC("fft1");
         // ---- 64-point inverse DFT as 8 x 8: x[8q+p] = sum_l W8^{lq} W64^{lp} sum_m X[l+8m] W8^{mp}
         // (s_tw holds W64^{lp} times the output scale, so no separate scaling pass is needed)
         if (type == 1) {
@@ -628,6 +623,7 @@ __device__ inline void modulate_group(int type, uint32_t pre_row, uint64_t W, ui
         wave_sync();
     }
 
+    SEC("fft2");
     // ---- the row's 80 samples into the staging area.  Lane l owns samples l + 8i, i = 0..9:
     // symbol rows: out[o] = x[(o + 48) % 64] (cyclic prefix, examples/ftw_ofdm.py:121-123), so
     // i = 0,1 repeat q = 6,7 and i >= 2 is q = i - 2; preamble rows copy the table, gap rows are 0.
@@ -653,6 +649,7 @@ __device__ inline void modulate_group(int type, uint32_t pre_row, uint64_t W, ui
     for (int i = 0; i < 10; i++) buf[g * RS + l + 8 * i] = o10[i];
     wave_sync();
 
+    SEC("store");
     // ---- 8 rows = 5120 contiguous bytes, 16 B per lane per store: always five store
     // instructions per full group (k_modulate's counted wait relies on that); lanes beyond the
     // end of the stream are masked, which happens in a last, partial group only
@@ -679,12 +676,12 @@ constexpr int MOD_WAVES = 4;
 //   bits 2..4   bits per carrier       bits 5..9   bit offset of the lane's window in its first dword
 //   bits 10..16 LUT offset             bit 17      pilot polarity is -1
 //   bits 18..19 preamble row index
-__device__ inline int cw_type(uint32_t cw) { return (int)(cw & 3u); }
+__device__ __forceinline__ int cw_type(uint32_t cw) { return (int)(cw & 3u); }
 
 // Decode row `grp*8 + g`: returns the descriptor and the address of the lane's 8-byte message
 // window (src).  d0 = first data carrier among the lane's eight bins.
 template <bool UNIFORM>
-__device__ inline uint32_t prepare_row(const PlanParams &P, uint64_t pneg_lo, uint64_t pneg_hi, const uint8_t *msg,
+__device__ __forceinline__ uint32_t prepare_row(const PlanParams &P, uint64_t pneg_lo, uint64_t pneg_hi, const uint8_t *msg,
                                        uint32_t grp, uint32_t n_groups, int g, int d0,
                                        uint32_t pre_rows, const uint8_t *&src, uint32_t &map_row)
 {
@@ -895,12 +892,18 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads, float2 *__
     for (uint32_t p = blockIdx.x * TX_WAVES + wave; p < P.n_pkts; p += gridDim.x * TX_WAVES) {
         const Pkt k = load_pkt<UNIFORM>(P, p);
         const RegimeInfo ri = regime_info((int)k.regime);
+#ifndef TX_SKIP_ENC
         encode_packet(k, ri, T, payloads, A, U, s_crc, s_scr, lane, nullptr, nullptr, nullptr);
+#endif
 
         const uint32_t n_rows = pre_rows + 1u + k.n_sym + gap_rows;
         const size_t row0 = UNIFORM ? (size_t)p * P.rows_per_pkt : (size_t)P.row_start[p];
         float4 *out = reinterpret_cast<float4 *>(iq + row0 * SYM_LEN);
+#ifdef TX_SKIP_MOD
+        if (P.amp == 12345.f)
+#endif
         for (uint32_t r0 = 0; r0 < n_rows; r0 += 8u) {
+            SEC("prep");
             const uint32_t r = r0 + g;
             const int type = r >= n_rows ? 3 : (r < pre_rows ? 0 : (r - pre_rows <= k.n_sym ? 1 : 2));
             uint64_t W = 0;
@@ -921,6 +924,7 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads, float2 *__
             modulate_group(type, r, W, nb, lut_off, pil, 0u, nullptr, kinds, d0, l, g, lane, buf, s_lut, s_pre,
                            s_tw, swap_iq, out + (size_t)r0 * (SYM_LEN / 2),
                            n_rows - r0 < 8u ? n_rows - r0 : 8u);
+            SEC("end");
             wave_sync();
         }
     }
