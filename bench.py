@@ -3,15 +3,16 @@
 
     python bench.py --gpus N --steps K --warmup W [--packets P]
 
-One "step" is one pass of the transmit chain (bit-level kernel + fused map/IFFT/CP kernel)
-over one batch of P synthetic packets per GPU, payloads already resident in HBM.  With N > 1
+One "step" is one pass of the transmit chain over one batch of P synthetic packets per GPU,
+payloads already resident in HBM: by default the fused kernel k_tx (payload -> IQ, the mapper
+bits never leave the CU); --fused 0 times the two-kernel path (k_encode_bits + k_modulate).  With N > 1
 (launched by torch.distributed.run, one rank per GPU) the batch is sharded by packet index:
 every rank processes its own P packets, there is no collective on the data path, and the
 reported value is all ranks' samples divided by the slowest rank's time (weak scaling).
 
-Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (k_modulate) against
-the HBM peak from its algorithmic bytes and its launch time measured with events on the
-launch stream; `cpu_baseline` times the plain-C oracle port on the host cores (N = 1 only).
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (k_tx, or k_modulate with
+--fused 0) against the HBM peak from its algorithmic bytes and its launch time measured with
+events on the launch stream; `cpu_baseline` times the plain-C oracle port on the host cores (N = 1 only).
 """
 import argparse
 import json
@@ -59,7 +60,7 @@ def cpu_baseline(n_sample, threads):
 
 
 def load_traffic(workload_key):
-    """HBM bytes per k_modulate launch from the committed PMC passes (profiles/), or None."""
+    """HBM bytes per launch of the named kernel from the committed PMC passes (profiles/), or None."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
@@ -75,8 +76,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--packets", type=int, default=1_000_000, help="packets per GPU per step")
-    ap.add_argument("--fused", type=int, default=0, help="1: single fused kernel (ofdmtx_tx), 0: two kernels")
-    ap.add_argument("--cpu-sample", type=int, default=40_000, help="packets timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--fused", type=int, default=1, help="1: single fused kernel (ofdmtx_tx), 0: two kernels")
+    ap.add_argument("--stage-steps", type=int, default=3, help="untimed extra passes of the two-kernel path")
+    ap.add_argument("--cpu-sample", type=int, default=100_000, help="packets timed on the CPU baseline (0 = skip)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -104,20 +106,19 @@ def main():
     iq = plan.alloc_iq()
 
     def step(events=None):
-        if a.fused:
-            if events is not None:
-                events[0].record()
-                events[1].record()
-            plan.tx(payloads, out=iq, work=msg)
-            if events is not None:
-                events[2].record()
-            return
+        """One pass of the transmit chain over the batch.  events (start, mid, end) are recorded on
+        the launch stream around the kernels."""
         if events is not None:
             events[0].record()
-        plan.encode_bits(payloads, out=msg)
-        if events is not None:
-            events[1].record()
-        plan.modulate(msg, out=iq)
+        if a.fused:
+            plan.tx(payloads, out=iq, work=msg)          # k_tx: payload -> IQ in one kernel
+            if events is not None:
+                events[1].record()
+        else:
+            plan.encode_bits(payloads, out=msg)          # k_encode_bits
+            if events is not None:
+                events[1].record()
+            plan.modulate(msg, out=iq)                   # k_modulate
         if events is not None:
             events[2].record()
 
@@ -141,15 +142,37 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    enc_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
-    mod_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))
+    first_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
+    second_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))
+
+    # the two-kernel path, outside the timed region, for the per-stage numbers
+    stage = None
+    if a.fused and rank == 0 and a.stage_steps > 0:
+        plan.encode_bits(payloads, out=msg)
+        plan.modulate(msg, out=iq)
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(a.stage_steps)]
+        for e in ev:
+            e[0].record()
+            plan.encode_bits(payloads, out=msg)
+            e[1].record()
+            plan.modulate(msg, out=iq)
+            e[2].record()
+        torch.cuda.synchronize()
+        stage = (float(np.mean([e[0].elapsed_time(e[1]) for e in ev])),
+                 float(np.mean([e[1].elapsed_time(e[2]) for e in ev])))
 
     if rank == 0:
         samples_per_step = world * plan.n_samples
         value = samples_per_step * a.steps / dt / 1e6
-        alg_bytes = n * (info.msg_len + info.n_rows * 640)     # mapper message read + IQ rows written
-        achieved = alg_bytes / (mod_ms * 1e-3) / 1e9
-        workload_key = "mod_54M_1500B_%dpk" % n
+        if a.fused:
+            kernel, kernel_ms = "k_tx", first_ms
+            alg_bytes = n * (PAYLOAD + info.n_rows * 640)          # payload read + IQ rows written
+            kernels = {"k_tx": first_ms}
+        else:
+            kernel, kernel_ms = "k_modulate", second_ms
+            alg_bytes = n * (info.msg_len + info.n_rows * 640)     # mapper message read + IQ rows written
+            kernels = {"k_encode_bits": first_ms, "k_modulate": second_ms}
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         out = {
             "metric": "baseband IQ Msamples/s (node), 802.11a 54Mbps 1500B packets",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -160,11 +183,17 @@ def main():
                                    % (n, info.n_sym),
                        "packets_per_gpu": n, "samples_per_packet": info.n_rows * 80,
                        "parallelism": "packets sharded by index over %d GPU(s), no collective" % world},
-            "kernel_ms": {"k_encode_bits": enc_ms, "k_modulate": mod_ms},
-            "roofline": {"bound": "hbm", "kernel": "k_modulate", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(workload_key),
+            "kernel_ms": kernels,
+            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": load_traffic("%s_54M_1500B_%dpk" % (kernel, n)),
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
+        if stage is not None:
+            mb = n * (info.msg_len + info.n_rows * 640)
+            out["two_kernel_path"] = {"k_encode_bits_ms": stage[0], "k_modulate_ms": stage[1],
+                                      "k_modulate_GBps": mb / (stage[1] * 1e-3) / 1e9,
+                                      "k_modulate_frac_of_peak": mb / (stage[1] * 1e-3) / 1e9 / HBM_PEAK_GBS}
         if world == 1 and a.cpu_sample > 0:
             threads = min(16, os.cpu_count() or 1)
             out["cpu_baseline"] = cpu_baseline(a.cpu_sample, threads)

@@ -238,11 +238,35 @@ __device__ constexpr int deinterleave(int j)
     return 16 * (S * (u / S) + ((u % S) + c) % S) + c;
 }
 
-template <int NBPSC, int PUNCT, int NA, int NW, int... J>
-__device__ __forceinline__ void interleave_bits(const uint32_t (&Aw)[NA], const uint32_t (&Bw)[NA],
-                                                uint32_t (&out)[NW], std::integer_sequence<int, J...>)
+// Bit t of interleaved word WORD (t = 0 is the MSB); bits beyond the symbol's N contribute 0.
+template <int NBPSC, int PUNCT, int WORD, int T, int NA>
+__device__ __forceinline__ uint32_t interleaved_bit(const uint32_t (&Aw)[NA], const uint32_t (&Bw)[NA])
 {
-    (move_coded_bit<PUNCT, J, deinterleave<NBPSC>(J)>(Aw, Bw, out), ...);
+    constexpr int J = 32 * WORD + T;
+    if constexpr (J >= 48 * NBPSC) {
+        return 0u;
+    } else {
+        constexpr int p = unpuncture<PUNCT>(deinterleave<NBPSC>(J)), n = p >> 1;
+        const uint32_t w = (p & 1) ? Bw[n >> 5] : Aw[n >> 5];
+        return ((w >> (31 - (n & 31))) & 1u) << (31 - T);
+    }
+}
+
+template <int NBPSC, int PUNCT, int WORD, int NA, int... T>
+__device__ __forceinline__ uint32_t interleaved_word(const uint32_t (&Aw)[NA], const uint32_t (&Bw)[NA],
+                                                     std::integer_sequence<int, T...>)
+{
+    return (interleaved_bit<NBPSC, PUNCT, WORD, T>(Aw, Bw) | ...);
+}
+
+// All words of the symbol, one after the other: the scheduling barrier keeps hipcc from hoisting
+// the bit extracts of every word to the front (which costs > 200 VGPRs and with them occupancy).
+template <int NBPSC, int PUNCT, int NA, int NW, int... WORD>
+__device__ __forceinline__ void interleave_bits(const uint32_t (&Aw)[NA], const uint32_t (&Bw)[NA],
+                                                uint32_t (&out)[NW], std::integer_sequence<int, WORD...>)
+{
+    ((out[WORD] = interleaved_word<NBPSC, PUNCT, WORD>(Aw, Bw, std::make_integer_sequence<int, 32>{}),
+      __builtin_amdgcn_sched_barrier(0)), ...);
 }
 
 template <int PUNCT, int NA, int NW, int... Q>
@@ -305,9 +329,7 @@ __device__ __forceinline__ void encode_data_symbols(const uint32_t *U, uint32_t 
         }
 
         uint32_t out[NW];
-#pragma unroll
-        for (int i = 0; i < NW; i++) out[i] = 0;
-        interleave_bits<NBPSC, PUNCT>(Aw, Bw, out, std::make_integer_sequence<int, N>{});
+        interleave_bits<NBPSC, PUNCT>(Aw, Bw, out, std::make_integer_sequence<int, NW>{});
 
         if (N % 32 == 0) {
 #pragma unroll
@@ -839,8 +861,10 @@ k_modulate(PlanParams P, DevTables T, const uint8_t *__restrict__ msg, float2 *_
 constexpr int TX_WAVES = 4;
 constexpr int TX_B_WORDS = 8 * RS * 2;
 
+// (second launch bound = 4 waves per SIMD: caps the kernel at 128 VGPRs; uncapped, hipcc spends
+//  ~250 on the encoder's bit table and halves the occupancy of the whole kernel)
 template <bool UNIFORM>
-__global__ void __launch_bounds__(64 * TX_WAVES)
+__global__ void __launch_bounds__(64 * TX_WAVES, 4)
 k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads, float2 *__restrict__ iq,
      uint32_t a_words)
 {
@@ -892,16 +916,11 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads, float2 *__
     for (uint32_t p = blockIdx.x * TX_WAVES + wave; p < P.n_pkts; p += gridDim.x * TX_WAVES) {
         const Pkt k = load_pkt<UNIFORM>(P, p);
         const RegimeInfo ri = regime_info((int)k.regime);
-#ifndef TX_SKIP_ENC
         encode_packet(k, ri, T, payloads, A, U, s_crc, s_scr, lane, nullptr, nullptr, nullptr);
-#endif
 
         const uint32_t n_rows = pre_rows + 1u + k.n_sym + gap_rows;
         const size_t row0 = UNIFORM ? (size_t)p * P.rows_per_pkt : (size_t)P.row_start[p];
         float4 *out = reinterpret_cast<float4 *>(iq + row0 * SYM_LEN);
-#ifdef TX_SKIP_MOD
-        if (P.amp == 12345.f)
-#endif
         for (uint32_t r0 = 0; r0 < n_rows; r0 += 8u) {
             SEC("prep");
             const uint32_t r = r0 + g;
