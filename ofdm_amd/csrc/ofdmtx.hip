@@ -349,6 +349,7 @@ __device__ __forceinline__ void encode_data_symbols(const uint32_t *U, uint32_t 
 // words of LDS (first the natural-order MPDU, finally the message words OUTW: OUTW[0] low half
 // and OUTW[1] = the 48 SIGNAL bits, OUTW[2..] = interleaved DATA bits, all MSB first);
 // U: >= n_words + 2 words.  plcp_out / scr_out / cod_out are optional taps (global memory).
+template <int REGIME>
 __device__ __forceinline__ void encode_packet(const Pkt &k, const RegimeInfo &ri, const DevTables &T,
                                      const uint8_t *__restrict__ payloads, uint32_t *A, uint32_t *U,
                                      const uint32_t *s_crc, const uint32_t *s_scr, int lane,
@@ -474,7 +475,9 @@ __device__ __forceinline__ void encode_packet(const Pkt &k, const RegimeInfo &ri
 
     SEC("e5_data");
     // ---- 5. DATA symbols
-    switch (k.regime) {
+    // REGIME != 0: the batch has one regime, known when the kernel was chosen, and only that
+    // instantiation is compiled in; REGIME == 0 (mixed-rate batches) dispatches per packet.
+    switch (REGIME ? (uint32_t)REGIME : k.regime) {
     case 1: encode_data_symbols<1, 0>(U, OUTW, k.n_sym, co, lane); break;
     case 2: encode_data_symbols<1, 1>(U, OUTW, k.n_sym, co, lane); break;
     case 3: encode_data_symbols<2, 0>(U, OUTW, k.n_sym, co, lane); break;
@@ -492,7 +495,7 @@ constexpr int ENC_WAVES = 4;
 constexpr int ENC_A_WORDS = 1600;   // natural MPDU (2 zero words + <= 792 words), later the message words
 constexpr int ENC_U_WORDS = MAX_PLCP / 4 + 4;
 
-template <bool UNIFORM>
+template <bool UNIFORM, int REGIME>
 __global__ void __launch_bounds__(64 * ENC_WAVES)
 k_encode_bits(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads,
               uint8_t *__restrict__ plcp_out, uint8_t *__restrict__ scr_out,
@@ -513,9 +516,9 @@ k_encode_bits(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads,
 
     for (uint32_t p = blockIdx.x * ENC_WAVES + wave; p < P.n_pkts; p += gridDim.x * ENC_WAVES) {
         const Pkt k = load_pkt<UNIFORM>(P, p);
-        const RegimeInfo ri = regime_info((int)k.regime);
+        const RegimeInfo ri = regime_info(REGIME ? REGIME : (int)k.regime);
         const uint32_t msg_len = 6u + k.n_sym * ri.n_cbps / 8u;
-        encode_packet(k, ri, T, payloads, A, U, s_crc, s_scr, lane, plcp_out, scr_out, cod_out);
+        encode_packet<REGIME>(k, ri, T, payloads, A, U, s_crc, s_scr, lane, plcp_out, scr_out, cod_out);
         uint32_t *OUTW = A;
 
         // ---- 6. message bytes = OUTW stream shifted by 16 bits (6 SIGNAL bytes lead)
@@ -863,7 +866,7 @@ constexpr int TX_B_WORDS = 8 * RS * 2;
 
 // (second launch bound = 4 waves per SIMD: caps the kernel at 128 VGPRs; uncapped, hipcc spends
 //  ~250 on the encoder's bit table and halves the occupancy of the whole kernel)
-template <bool UNIFORM>
+template <bool UNIFORM, int REGIME>
 __global__ void __launch_bounds__(64 * TX_WAVES, 4)
 k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads, float2 *__restrict__ iq,
      uint32_t a_words)
@@ -915,8 +918,8 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads, float2 *__
 
     for (uint32_t p = blockIdx.x * TX_WAVES + wave; p < P.n_pkts; p += gridDim.x * TX_WAVES) {
         const Pkt k = load_pkt<UNIFORM>(P, p);
-        const RegimeInfo ri = regime_info((int)k.regime);
-        encode_packet(k, ri, T, payloads, A, U, s_crc, s_scr, lane, nullptr, nullptr, nullptr);
+        const RegimeInfo ri = regime_info(REGIME ? REGIME : (int)k.regime);
+        encode_packet<REGIME>(k, ri, T, payloads, A, U, s_crc, s_scr, lane, nullptr, nullptr, nullptr);
 
         const uint32_t n_rows = pre_rows + 1u + k.n_sym + gap_rows;
         const size_t row0 = UNIFORM ? (size_t)p * P.rows_per_pkt : (size_t)P.row_start[p];
@@ -1370,12 +1373,26 @@ int ofdmtx_encode_bits(ofdmtx_ctx *ctx, const ofdmtx_plan *pl, const uint8_t *d_
     HIPCHK(hipSetDevice(ctx->device));
     const int grid = grid_for(ctx, pl->pp.n_pkts, ENC_WAVES, 8);
     hipStream_t st = (hipStream_t)stream;
-    if (pl->pp.uniform)
-        hipLaunchKernelGGL(k_encode_bits<true>, dim3(grid), dim3(64 * ENC_WAVES), 0, st, pl->pp,
-                           ctx->tables(), d_payloads, d_plcp, d_scrambled, d_coded, d_interleaved);
-    else
-        hipLaunchKernelGGL(k_encode_bits<false>, dim3(grid), dim3(64 * ENC_WAVES), 0, st, pl->pp,
-                           ctx->tables(), d_payloads, d_plcp, d_scrambled, d_coded, d_interleaved);
+    const PlanParams &pp = pl->pp;
+    const DevTables tab = ctx->tables();
+#define LAUNCH_ENC(U_, R_)                                                                           \
+    hipLaunchKernelGGL((k_encode_bits<U_, R_>), dim3(grid), dim3(64 * ENC_WAVES), 0, st, pp, tab,    \
+                       d_payloads, d_plcp, d_scrambled, d_coded, d_interleaved)
+    if (!pp.uniform) {
+        LAUNCH_ENC(false, 0);
+    } else {
+        switch (pp.regime) {
+        case 1: LAUNCH_ENC(true, 1); break;
+        case 2: LAUNCH_ENC(true, 2); break;
+        case 3: LAUNCH_ENC(true, 3); break;
+        case 4: LAUNCH_ENC(true, 4); break;
+        case 5: LAUNCH_ENC(true, 5); break;
+        case 6: LAUNCH_ENC(true, 6); break;
+        case 7: LAUNCH_ENC(true, 7); break;
+        default: LAUNCH_ENC(true, 8); break;
+        }
+    }
+#undef LAUNCH_ENC
     HIPCHK(hipGetLastError());
     return OFDMTX_OK;
 }
@@ -1412,12 +1429,28 @@ int ofdmtx_tx(ofdmtx_ctx *ctx, const ofdmtx_plan *pl, const uint8_t *d_payloads,
     const int grid = grid_for(ctx, pl->pp.n_pkts, TX_WAVES, 8);
     const size_t lds = (size_t)TX_WAVES * (pl->tx_a_words + TX_B_WORDS) * sizeof(uint32_t);
     hipStream_t st = (hipStream_t)stream;
-    if (pl->pp.uniform)
-        hipLaunchKernelGGL(k_tx<true>, dim3(grid), dim3(64 * TX_WAVES), lds, st, pl->pp, ctx->tables(),
-                           d_payloads, reinterpret_cast<float2 *>(d_iq), pl->tx_a_words);
-    else
-        hipLaunchKernelGGL(k_tx<false>, dim3(grid), dim3(64 * TX_WAVES), lds, st, pl->pp, ctx->tables(),
-                           d_payloads, reinterpret_cast<float2 *>(d_iq), pl->tx_a_words);
+    const PlanParams &pp = pl->pp;
+    const DevTables tab = ctx->tables();
+    float2 *iq = reinterpret_cast<float2 *>(d_iq);
+    const uint32_t a_words = pl->tx_a_words;
+#define LAUNCH_TX(U_, R_)                                                                            \
+    hipLaunchKernelGGL((k_tx<U_, R_>), dim3(grid), dim3(64 * TX_WAVES), lds, st, pp, tab, d_payloads, \
+                       iq, a_words)
+    if (!pp.uniform) {
+        LAUNCH_TX(false, 0);
+    } else {
+        switch (pp.regime) {
+        case 1: LAUNCH_TX(true, 1); break;
+        case 2: LAUNCH_TX(true, 2); break;
+        case 3: LAUNCH_TX(true, 3); break;
+        case 4: LAUNCH_TX(true, 4); break;
+        case 5: LAUNCH_TX(true, 5); break;
+        case 6: LAUNCH_TX(true, 6); break;
+        case 7: LAUNCH_TX(true, 7); break;
+        default: LAUNCH_TX(true, 8); break;
+        }
+    }
+#undef LAUNCH_TX
     HIPCHK(hipGetLastError());
     return OFDMTX_OK;
 }
