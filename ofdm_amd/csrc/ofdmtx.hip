@@ -49,7 +49,12 @@ constexpr int MAX_PLCP = 3264;        // 5 + 3168 + 28 tail/pad bytes, rounded u
 constexpr int SYM_LEN = 80;           // examples/ftw_ofdm.py:75
 constexpr int PRE_ROWS = 4;           // ftw/ftw_ofdm_preamble.cc:79
 constexpr int GAP_ROWS = 13;          // ftw/ftw_zerogap.cc:88
-constexpr int LUT_SIZE = 88;          // [0,2) SIGNAL BPSK, then bpsk@2 qpsk@4 qam16@8 qam64@24
+// Constellation LUT slots (complex entries).  Every table starts at a power of two at least
+// its size, so that slot = offset | index:
+//   0 zero (null carriers) | 2 (-1,0), 3 (+1,0): SIGNAL BPSK and the pilots | 4,5 BPSK | 8..11 QPSK
+//   | 16..31 16-QAM | 64..127 64-QAM
+constexpr int LUT_SIZE = 128;
+constexpr int LUT_PM1 = 2;            // slot of -1; +1 follows
 
 struct RegimeInfo {
     int n_cbps, n_bpsc, n_dbps, rate_bits, punct, lut_off;   // punct: 0 none, 1 = 3/4, 2 = 2/3
@@ -59,14 +64,14 @@ struct RegimeInfo {
 __host__ __device__ __forceinline__ RegimeInfo regime_info(int regime)
 {
     switch (regime) {
-    case 1: return {48, 1, 24, 0x0D, 0, 2};
-    case 2: return {48, 1, 36, 0x0F, 1, 2};
-    case 3: return {96, 2, 48, 0x05, 0, 4};
-    case 4: return {96, 2, 72, 0x07, 1, 4};
-    case 5: return {192, 4, 96, 0x09, 0, 8};
-    case 6: return {192, 4, 144, 0x0B, 1, 8};
-    case 7: return {288, 6, 192, 0x01, 2, 24};
-    default: return {288, 6, 216, 0x03, 1, 24};
+    case 1: return {48, 1, 24, 0x0D, 0, 4};
+    case 2: return {48, 1, 36, 0x0F, 1, 4};
+    case 3: return {96, 2, 48, 0x05, 0, 8};
+    case 4: return {96, 2, 72, 0x07, 1, 8};
+    case 5: return {192, 4, 96, 0x09, 0, 16};
+    case 6: return {192, 4, 144, 0x0B, 1, 16};
+    case 7: return {288, 6, 192, 0x01, 2, 64};
+    default: return {288, 6, 216, 0x03, 1, 64};
     }
 }
 
@@ -158,6 +163,18 @@ __device__ __forceinline__ void wave_sync()
 {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+}
+
+// What FFT bin k carries: ftw/ftw_ofdm_pilot_cc.cc:119-155 then ftw/ftw_ofdm_cmap_cc.cc:102-107.
+//   >= 0 : data carrier index 0..47;  -1 : null;  -2 : pilot with +p;  -3 : pilot with -p
+__host__ __device__ constexpr int bin_code(int k)
+{
+    const int f = k < 32 ? k : k - 64;
+    if (f == 0 || f > 26 || f < -26) return -1;
+    if (f == -21 || f == -7 || f == 7) return -2;
+    if (f == 21) return -3;
+    const int t = f + 26;
+    return t - (t > 5) - (t > 19) - (t > 26) - (t > 33) - (t > 47);
 }
 
 // ======================================================================================
@@ -345,15 +362,13 @@ __device__ __forceinline__ void encode_data_symbols(const uint32_t *U, uint32_t 
     }
 }
 
-// Steps 1-5 for one packet, executed by one wavefront.  A: >= max(n_words + 3, message words + 4)
-// words of LDS (first the natural-order MPDU, finally the message words OUTW: OUTW[0] low half
-// and OUTW[1] = the 48 SIGNAL bits, OUTW[2..] = interleaved DATA bits, all MSB first);
-// U: >= n_words + 2 words.  plcp_out / scr_out / cod_out are optional taps (global memory).
-template <int REGIME>
-__device__ __forceinline__ void encode_packet(const Pkt &k, const RegimeInfo &ri, const DevTables &T,
-                                     const uint8_t *__restrict__ payloads, uint32_t *A, uint32_t *U,
-                                     const uint32_t *s_crc, const uint32_t *s_scr, int lane,
-                                     uint8_t *plcp_out, uint8_t *scr_out, uint8_t *cod_out)
+// Steps 1-3 for one packet, executed by one wavefront: the scrambled PLCP stream as MSB-first
+// words in U[0 .. n_words].  A: >= n_words + 3 words of LDS (natural-order MPDU, dead afterwards);
+// U: >= n_words + 2 words.  plcp_out / scr_out are optional taps (global memory).
+__device__ __forceinline__ void scramble_packet(const Pkt &k, const RegimeInfo &ri, const DevTables &T,
+                                                const uint8_t *__restrict__ payloads, uint32_t *A, uint32_t *U,
+                                                const uint32_t *s_crc, const uint32_t *s_scr, int lane,
+                                                uint8_t *plcp_out, uint8_t *scr_out)
 {
     const uint32_t mpdu_len = 24u + k.pay_len;
     const uint32_t length = mpdu_len + 4u;                                   // pu:193
@@ -446,6 +461,19 @@ __device__ __forceinline__ void encode_packet(const Pkt &k, const RegimeInfo &ri
         }
     }
     wave_sync();
+}
+
+// Steps 1-5 for one packet, executed by one wavefront.  A: >= max(n_words + 3, message words + 4)
+// words of LDS (first the natural-order MPDU, finally the message words OUTW: OUTW[0] low half
+// and OUTW[1] = the 48 SIGNAL bits, OUTW[2..] = interleaved DATA bits, all MSB first);
+// U: >= n_words + 2 words.  plcp_out / scr_out / cod_out are optional taps (global memory).
+template <int REGIME>
+__device__ __forceinline__ void encode_packet(const Pkt &k, const RegimeInfo &ri, const DevTables &T,
+                                     const uint8_t *__restrict__ payloads, uint32_t *A, uint32_t *U,
+                                     const uint32_t *s_crc, const uint32_t *s_scr, int lane,
+                                     uint8_t *plcp_out, uint8_t *scr_out, uint8_t *cod_out)
+{
+    scramble_packet(k, ri, T, payloads, A, U, s_crc, s_scr, lane, plcp_out, scr_out);
 
     SEC("e4_signal");
     // ---- 4. SIGNAL symbol: 48 coded bits, N = 48 first permutation only (pu:245-249)
@@ -489,6 +517,147 @@ __device__ __forceinline__ void encode_packet(const Pkt &k, const RegimeInfo &ri
     }
     wave_sync();
 
+}
+
+// --------------------------------------------------------------------------------------
+// Slot rows (fused kernel): instead of message bits, the encoder can emit for every OFDM symbol
+// the constellation-LUT slot of each of its 52 occupied FFT bins, one byte per bin.  The bytes
+// are grouped by l = bin % 8 -- the lane that feeds the bin to the first radix-8 stage -- and
+// ascend by bin inside a group, so lane l finds its bins l, l+8, .. l+56 (nulls left out) in
+// one short byte window.  A row is 52 bytes = 13 words; with that odd word stride the
+// lane-per-symbol row writes are free of LDS bank conflicts.
+constexpr int SLOT_ROW_WORDS = 13;
+
+constexpr int slot_row_bin(int rb)            // FFT bin of row byte rb
+{
+    int n = 0;
+    for (int l = 0; l < 8; l++)
+        for (int m = 0; m < 8; m++)
+            if (bin_code(l + 8 * m) != -1) {
+                if (n == rb) return l + 8 * m;
+                n++;
+            }
+    return 0;                                 // not reached for rb < 52; bin 0 is a null
+}
+
+constexpr int slot_seg_off(int l)             // first row byte of lane l's group
+{
+    int n = 0;
+    for (int ll = 0; ll < l; ll++)
+        for (int m = 0; m < 8; m++)
+            if (bin_code(ll + 8 * m) != -1) n++;
+    return n;
+}
+
+template <int RB>
+struct SlotCode { static constexpr int value = bin_code(slot_row_bin(RB)); };
+
+// bin_code of the bin behind row byte `rb` (rb >= 52: -1), by compile-time selects
+template <int... RB>
+__device__ __forceinline__ int slot_code_of(int rb, std::integer_sequence<int, RB...>)
+{
+    int c = -1;
+    ((c = rb == RB ? SlotCode<RB>::value : c), ...);
+    return c;
+}
+
+constexpr int lut_off_for(int nbpsc) { return nbpsc == 1 ? 4 : nbpsc == 2 ? 8 : nbpsc == 4 ? 16 : 64; }
+
+// ftw/ftw_ofdm_pilot_cc.cc:116,159: polarity of the pilots of the symbol with running index pidx
+__device__ __forceinline__ uint32_t pilot_negative(uint32_t pidx, uint64_t pneg_lo, uint64_t pneg_hi)
+{
+    return (uint32_t)((pidx < 64u ? pneg_lo : pneg_hi) >> (pidx & 63u)) & 1u;
+}
+
+// Bit I of slot word WORD: byte I / NBPSC, constellation index bit t = I % NBPSC (t = 0 is the
+// index MSB: ftw/ftw_ofdm_mapper.cc:262-275 consumes the message MSB first).
+template <int NBPSC, int PUNCT, int WORD, int I, int NA>
+__device__ __forceinline__ uint32_t slot_bit(const uint32_t (&Aw)[NA], const uint32_t (&Bw)[NA])
+{
+    constexpr int b = I / NBPSC, t = I % NBPSC;
+    constexpr int c = SlotCode<4 * WORD + b>::value;
+    if constexpr (c < 0) {
+        return 0u;
+    } else {
+        constexpr int p = unpuncture<PUNCT>(deinterleave<NBPSC>(NBPSC * c + t)), n = p >> 1;
+        const uint32_t w = (p & 1) ? Bw[n >> 5] : Aw[n >> 5];
+        return ((w >> (31 - (n & 31))) & 1u) << (8 * b + NBPSC - 1 - t);
+    }
+}
+
+// constant part of slot word WORD (LUT offsets of data bytes, pilots for polarity +1) and the
+// mask of the bits that flip when the polarity is -1
+template <int NBPSC, int WORD>
+struct SlotConst {
+    static constexpr uint32_t byte_const(int b)
+    {
+        const int c = bin_code(slot_row_bin(4 * WORD + b));
+        return (uint32_t)(c >= 0 ? lut_off_for(NBPSC) : c == -2 ? LUT_PM1 + 1 : c == -3 ? LUT_PM1 : 0) << (8 * b);
+    }
+    static constexpr uint32_t byte_flip(int b)
+    {
+        const int c = bin_code(slot_row_bin(4 * WORD + b));
+        return (uint32_t)(c == -2 || c == -3 ? 1 : 0) << (8 * b);
+    }
+    static constexpr uint32_t value = byte_const(0) | byte_const(1) | byte_const(2) | byte_const(3);
+    static constexpr uint32_t flip = byte_flip(0) | byte_flip(1) | byte_flip(2) | byte_flip(3);
+};
+
+template <int NBPSC, int PUNCT, int WORD, int NA, int... I>
+__device__ __forceinline__ uint32_t slot_word(const uint32_t (&Aw)[NA], const uint32_t (&Bw)[NA], uint32_t neg,
+                                              std::integer_sequence<int, I...>)
+{
+    uint32_t v = (slot_bit<NBPSC, PUNCT, WORD, I>(Aw, Bw) | ...) | SlotConst<NBPSC, WORD>::value;
+    if constexpr (SlotConst<NBPSC, WORD>::flip != 0u) v ^= neg ? SlotConst<NBPSC, WORD>::flip : 0u;
+    return v;
+}
+
+template <int NBPSC, int PUNCT, int NA, int... WORD>
+__device__ __forceinline__ void slot_words(const uint32_t (&Aw)[NA], const uint32_t (&Bw)[NA], uint32_t neg,
+                                           uint32_t (&out)[SLOT_ROW_WORDS], std::integer_sequence<int, WORD...>)
+{
+    ((out[WORD] = slot_word<NBPSC, PUNCT, WORD>(Aw, Bw, neg, std::make_integer_sequence<int, 4 * NBPSC>{}),
+      __builtin_amdgcn_sched_barrier(0)), ...);
+}
+
+// Slot rows of the DATA symbols c0 + lane (symbol 0 is SIGNAL and is not handled here), one
+// lane per symbol, into SI row `lane`.  Encoder, puncturing and interleaver as in
+// encode_data_symbols; pilot polarity of symbol index sidx is entry (pilot_base + sidx) % 127.
+template <int NBPSC, int PUNCT>
+__device__ __forceinline__ void symbol_slots(const uint32_t *U, uint32_t *SI, uint32_t c0, uint32_t n_sym,
+                                             uint32_t pilot_base, uint64_t pneg_lo, uint64_t pneg_hi, int lane)
+{
+    constexpr int N = 48 * NBPSC;
+    constexpr int NDBPS = PUNCT == 0 ? N / 2 : (PUNCT == 1 ? N * 3 / 4 : N * 2 / 3);
+    constexpr int NA = (NDBPS + 31) / 32;
+    constexpr int NX = NA + 1;
+
+    const uint32_t sidx = c0 + (uint32_t)lane;
+    if (sidx >= 1u && sidx <= n_sym) {
+        const uint32_t b0 = 18u + (sidx - 1u) * NDBPS;
+        const uint32_t w0 = b0 >> 5, o = b0 & 31u;
+        uint32_t X[NX];
+#pragma unroll
+        for (int i = 0; i < NX; i++) X[i] = __funnelshift_l(U[w0 + i + 1], U[w0 + i], o);
+        uint32_t Aw[NA], Bw[NA];
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            const uint32_t y0 = X[i];
+            const uint32_t y1 = __funnelshift_l(X[i + 1], X[i], 1);
+            const uint32_t y3 = __funnelshift_l(X[i + 1], X[i], 3);
+            const uint32_t y4 = __funnelshift_l(X[i + 1], X[i], 4);
+            const uint32_t y5 = __funnelshift_l(X[i + 1], X[i], 5);
+            const uint32_t y6 = __funnelshift_l(X[i + 1], X[i], 6);
+            const uint32_t common = y6 ^ y3 ^ y0;
+            Aw[i] = common ^ y4 ^ y1;
+            Bw[i] = common ^ y5 ^ y4;
+        }
+        const uint32_t neg = pilot_negative((pilot_base + sidx) % 127u, pneg_lo, pneg_hi);
+        uint32_t out[SLOT_ROW_WORDS];
+        slot_words<NBPSC, PUNCT>(Aw, Bw, neg, out, std::make_integer_sequence<int, SLOT_ROW_WORDS>{});
+#pragma unroll
+        for (int i = 0; i < SLOT_ROW_WORDS; i++) SI[SLOT_ROW_WORDS * lane + i] = out[i];
+    }
 }
 
 constexpr int ENC_WAVES = 4;
@@ -540,10 +709,28 @@ k_encode_bits(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads,
 // (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: two floats per instruction).
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ v2f rot90(v2f a) { return (v2f){-a.y, a.x}; }          // * (+j)
-__device__ __forceinline__ v2f cmul(v2f a, v2f b)                                  // a * b
+// The packed-f32 operand modifiers (op_sel picks the half that feeds each result lane, neg_lo /
+// neg_hi negate per lane) make multiplication by +-j free; hipcc does not use them for that (it
+// emits an xor and a move per rotation), hence the inline assembly.
+__device__ __forceinline__ v2f add_j(v2f a, v2f b)     // a + j*b = (a.x - b.y, a.y + b.x)
 {
-    return __builtin_elementwise_fma((v2f){a.y, a.y}, rot90(b), (v2f){a.x, a.x} * b);
+    v2f d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ v2f sub_j(v2f a, v2f b)     // a - j*b = (a.x + b.y, a.y - b.x)
+{
+    v2f d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ v2f cmul(v2f a, v2f b)      // a * b
+{
+    v2f t, d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));                 // a.x * (b.x, b.y)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"          // + a.y * (-b.y, b.x)
+        : "=v"(d) : "v"(a), "v"(b), "v"(t));
+    return d;
 }
 
 // y[p] = sum_m x[m] e^{+j 2 pi m p / 8}, in place
@@ -555,39 +742,116 @@ __device__ __forceinline__ void idft8(v2f (&x)[8])
     const v2f a4 = x[1] + x[5], a5 = x[1] - x[5];
     const v2f a6 = x[3] + x[7], a7 = x[3] - x[7];
     const v2f b0 = a0 + a2, b2 = a0 - a2;
-    const v2f b1 = a1 + rot90(a3), b3 = a1 - rot90(a3);
+    const v2f b1 = add_j(a1, a3), b3 = sub_j(a1, a3);
     const v2f b4 = a4 + a6, b6 = a4 - a6;
-    const v2f b5 = a5 + rot90(a7), b7 = a5 - rot90(a7);
-    const v2f t5 = b5 + rot90(b5);                 // b5 * e^{+j pi/4}  = h * t5
-    const v2f t7 = rot90(b7) - b7;                 // b7 * e^{+j 3pi/4} = h * t7
-    const v2f w6 = rot90(b6);
+    const v2f b5 = add_j(a5, a7), b7 = sub_j(a5, a7);
+    const v2f t5 = add_j(b5, b5);                  // b5 * e^{+j pi/4}  =  h * t5
+    const v2f t7 = sub_j(b7, b7);                  // b7 * e^{+j 3pi/4} = -h * t7
     x[0] = b0 + b4; x[4] = b0 - b4;
     x[1] = __builtin_elementwise_fma(h, t5, b1); x[5] = __builtin_elementwise_fma(-h, t5, b1);
-    x[2] = b2 + w6; x[6] = b2 - w6;
-    x[3] = __builtin_elementwise_fma(h, t7, b3); x[7] = __builtin_elementwise_fma(-h, t7, b3);
-}
-
-// What FFT bin k carries: ftw/ftw_ofdm_pilot_cc.cc:119-155 then ftw/ftw_ofdm_cmap_cc.cc:102-107.
-//   >= 0 : data carrier index 0..47;  -1 : null;  -2 : pilot with +p;  -3 : pilot with -p
-__device__ __forceinline__ int bin_code(int k)
-{
-    int f = k < 32 ? k : k - 64;
-    if (f == 0 || f > 26 || f < -26) return -1;
-    if (f == -21 || f == -7 || f == 7) return -2;
-    if (f == 21) return -3;
-    int t = f + 26;
-    return t - (t > 5) - (t > 19) - (t > 26) - (t > 33) - (t > 47);
+    x[2] = add_j(b2, b6); x[6] = sub_j(b2, b6);
+    x[3] = __builtin_elementwise_fma(-h, t7, b3); x[7] = __builtin_elementwise_fma(h, t7, b3);
 }
 
 constexpr int TG = 72;   // float2 per symbol in the transposition layout (8 rows x 9)
 constexpr int RS = 88;   // float2 per row in the staging layout
 
-// One group of 8 consecutive output rows by one wavefront, 8 lanes per row (lane = 8*g + l):
-// mapping -> 64-point inverse DFT -> cyclic prefix / preamble / gap -> coalesced stores.
+// Second half of a group of 8 consecutive output rows by one wavefront, 8 lanes per row
+// (lane = 8*g + l): 64-point inverse DFT -> cyclic prefix / preamble / gap -> coalesced stores.
 //   type 0 preamble row `pre_row`, 1 OFDM symbol, 2 zero-gap row, 3 no row
+//   x     (type 1) the lane's decimated carriers X[l + 8m], m = 0..7
+//   buf   the wave's LDS area of 8*RS float2; dst = first of the group's `rows_here` rows
+// SYM_ONLY: every row is of type 1 or 3 (the fused kernel copies preamble and gap rows itself).
+template <bool SYM_ONLY>
+__device__ __forceinline__ void ifft64_emit(int type, uint32_t pre_row, v2f (&x)[8], bool any_symbol, int l, int g,
+                                            int lane, v2f *buf, const v2f *s_pre, const v2f *s_tw, bool swap_iq,
+                                            float4 *__restrict__ dst, uint32_t rows_here)
+{
+    SEC("fft1");
+    // ---- 64-point inverse DFT as 8 x 8: x[8q+p] = sum_l W8^{lq} W64^{lp} sum_m X[l+8m] W8^{mp}
+    // (s_tw holds W64^{lp} times the output scale, so no separate scaling pass is needed)
+    if (any_symbol) {
+        if (type == 1) {
+            idft8(x);
+#pragma unroll
+            for (int p = 0; p < 8; p++) x[p] = cmul(x[p], s_tw[8 * p + l]);
+#pragma unroll
+            for (int p = 0; p < 8; p++) buf[g * TG + 9 * p + l] = x[p];
+        }
+        wave_sync();
+        if (type == 1) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) x[i] = buf[g * TG + 9 * l + i];   // lane now plays p = l
+        }
+        wave_sync();
+    }
+
+    SEC("fft2");
+    // ---- the row's 80 samples into the staging area.  Lane l owns samples l + 8i, i = 0..9:
+    // symbol rows: out[o] = x[(o + 48) % 64] (cyclic prefix, examples/ftw_ofdm.py:121-123), so
+    // i = 0,1 repeat q = 6,7 and i >= 2 is q = i - 2; preamble rows copy the table, gap rows are 0.
+    // I/Q exchange (examples/ftw_ofdm.py:155-163) sits in a branch the compiler must keep (the
+    // empty asm): turned into selects it would cost every launch 20 instructions per group.
+    if constexpr (SYM_ONLY) {
+        if (type == 1) {
+            idft8(x);                                                 // x[q] = sample 8q + l
+            if (swap_iq) {
+                asm volatile("");
+#pragma unroll
+                for (int q = 0; q < 8; q++) x[q] = (v2f){x[q].y, x[q].x};
+            }
+#pragma unroll
+            for (int i = 0; i < 10; i++) buf[g * RS + l + 8 * i] = x[(i + 6) & 7];
+        }
+    } else {
+        v2f o10[10];
+        if (type == 1) {
+            idft8(x);
+            o10[0] = x[6];
+            o10[1] = x[7];
+#pragma unroll
+            for (int q = 0; q < 8; q++) o10[q + 2] = x[q];
+        } else if (type == 0) {
+#pragma unroll
+            for (int i = 0; i < 10; i++) o10[i] = s_pre[pre_row * SYM_LEN + l + 8 * i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 10; i++) o10[i] = (v2f){0.f, 0.f};
+        }
+        if (swap_iq) {
+            asm volatile("");
+#pragma unroll
+            for (int i = 0; i < 10; i++) o10[i] = (v2f){o10[i].y, o10[i].x};
+        }
+#pragma unroll
+        for (int i = 0; i < 10; i++) buf[g * RS + l + 8 * i] = o10[i];
+    }
+    wave_sync();
+
+    SEC("store");
+    // ---- 8 rows = 5120 contiguous bytes, 16 B per lane per store: always five store
+    // instructions per full group (k_modulate's counted wait relies on that); lanes beyond the
+    // end of the stream are masked, which happens in a last, partial group only
+    if (rows_here == 8u) {
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            const int e = i * 64 + lane;              // float4 index, 40 per row
+            dst[e] = *reinterpret_cast<const float4 *>(buf + (e / 40) * RS + (e % 40) * 2);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            const int e = i * 64 + lane;
+            if ((uint32_t)e < rows_here * 40u)
+                dst[e] = *reinterpret_cast<const float4 *>(buf + (e / 40) * RS + (e % 40) * 2);
+        }
+    }
+}
+
+// One group of 8 consecutive output rows from mapper message bits (k_modulate):
+// mapping -> ifft64_emit.
 //   W     the lane's 64 message bits, first wanted bit at bit 63 (bins 8l..8l+7, nb bits each)
 //   kinds 2 bits per bin: 0 null, 1 data, 2 pilot +p, 3 pilot -p; d0 = first data carrier of the lane
-//   buf   the wave's LDS area of 8*RS float2; dst = first of the group's `rows_here` rows
 __device__ __forceinline__ void modulate_group(int type, uint32_t pre_row, uint64_t W, uint32_t nb, uint32_t lut_off,
                                       float pil, uint32_t map_row, float2 *__restrict__ mapped,
                                       uint32_t kinds, int d0, int l, int g, int lane, float2 *buf_,
@@ -596,8 +860,6 @@ __device__ __forceinline__ void modulate_group(int type, uint32_t pre_row, uint6
 {
     v2f *buf = reinterpret_cast<v2f *>(buf_);
     const v2f *s_lut = reinterpret_cast<const v2f *>(s_lut_);
-    const v2f *s_pre = reinterpret_cast<const v2f *>(s_pre_);
-    const v2f *s_tw = reinterpret_cast<const v2f *>(s_tw_);
     const bool any_symbol = __ballot(type == 1) != 0ull;
     v2f x[8];
 
@@ -624,74 +886,14 @@ __device__ __forceinline__ void modulate_group(int type, uint32_t pre_row, uint6
             }
         }
         wave_sync();
-
-        SEC("fft1");
-        // ---- 64-point inverse DFT as 8 x 8: x[8q+p] = sum_l W8^{lq} W64^{lp} sum_m X[l+8m] W8^{mp}
-        // (s_tw holds W64^{lp} times the output scale, so no separate scaling pass is needed)
         if (type == 1) {
 #pragma unroll
             for (int m = 0; m < 8; m++) x[m] = buf[g * TG + l + 9 * m];
         }
         wave_sync();
-        if (type == 1) {
-            idft8(x);
-#pragma unroll
-            for (int p = 0; p < 8; p++) x[p] = cmul(x[p], s_tw[8 * p + l]);
-#pragma unroll
-            for (int p = 0; p < 8; p++) buf[g * TG + 9 * p + l] = x[p];
-        }
-        wave_sync();
-        if (type == 1) {
-#pragma unroll
-            for (int i = 0; i < 8; i++) x[i] = buf[g * TG + 9 * l + i];   // lane now plays p = l
-        }
-        wave_sync();
     }
-
-    SEC("fft2");
-    // ---- the row's 80 samples into the staging area.  Lane l owns samples l + 8i, i = 0..9:
-    // symbol rows: out[o] = x[(o + 48) % 64] (cyclic prefix, examples/ftw_ofdm.py:121-123), so
-    // i = 0,1 repeat q = 6,7 and i >= 2 is q = i - 2; preamble rows copy the table, gap rows are 0.
-    v2f o10[10];
-    if (type == 1) {
-        idft8(x);                                                     // x[q] = sample 8q + l
-        o10[0] = x[6];
-        o10[1] = x[7];
-#pragma unroll
-        for (int q = 0; q < 8; q++) o10[q + 2] = x[q];
-    } else if (type == 0) {
-#pragma unroll
-        for (int i = 0; i < 10; i++) o10[i] = s_pre[pre_row * SYM_LEN + l + 8 * i];
-    } else {
-#pragma unroll
-        for (int i = 0; i < 10; i++) o10[i] = (v2f){0.f, 0.f};
-    }
-    if (swap_iq) {                                                    // examples/ftw_ofdm.py:155-163
-#pragma unroll
-        for (int i = 0; i < 10; i++) o10[i] = (v2f){o10[i].y, o10[i].x};
-    }
-#pragma unroll
-    for (int i = 0; i < 10; i++) buf[g * RS + l + 8 * i] = o10[i];
-    wave_sync();
-
-    SEC("store");
-    // ---- 8 rows = 5120 contiguous bytes, 16 B per lane per store: always five store
-    // instructions per full group (k_modulate's counted wait relies on that); lanes beyond the
-    // end of the stream are masked, which happens in a last, partial group only
-    if (rows_here == 8u) {
-#pragma unroll
-        for (int i = 0; i < 5; i++) {
-            const int e = i * 64 + lane;              // float4 index, 40 per row
-            dst[e] = *reinterpret_cast<const float4 *>(buf + (e / 40) * RS + (e % 40) * 2);
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 5; i++) {
-            const int e = i * 64 + lane;
-            if ((uint32_t)e < rows_here * 40u)
-                dst[e] = *reinterpret_cast<const float4 *>(buf + (e / 40) * RS + (e % 40) * 2);
-        }
-    }
+    ifft64_emit<false>(type, pre_row, x, any_symbol, l, g, lane, buf, reinterpret_cast<const v2f *>(s_pre_),
+                       reinterpret_cast<const v2f *>(s_tw_), swap_iq, dst, rows_here);
 }
 
 constexpr int MOD_WAVES = 4;
@@ -730,7 +932,7 @@ __device__ __forceinline__ uint32_t prepare_row(const PlanParams &P, uint64_t pn
     if (s > k.n_sym) return 2u;
     const RegimeInfo ri = regime_info((int)k.regime);
     const uint32_t nb = s == 0 ? 1u : (uint32_t)ri.n_bpsc;               // ftw/ftw_ofdm_mapper.cc:184-191
-    const uint32_t lut_off = s == 0 ? 0u : (uint32_t)ri.lut_off;
+    const uint32_t lut_off = s == 0 ? (uint32_t)LUT_PM1 : (uint32_t)ri.lut_off;
     const uint32_t bit0 = (s == 0 ? 0u : 48u + (s - 1u) * ri.n_cbps) + (uint32_t)d0 * nb;
     // up to 7 carriers x 6 bits + 7 bits of misalignment fit in 64 bits
     // (fetched as three ALIGNED dwords: unaligned 8-byte loads are several times slower)
@@ -855,13 +1057,20 @@ k_modulate(PlanParams P, DevTables T, const uint8_t *__restrict__ msg, float2 *_
 // Fused kernel: payload -> IQ, one wavefront per packet
 // ======================================================================================
 //
-// The wavefront encodes its packet into LDS (encode_packet) and then emits the packet's rows
-// group by group (modulate_group), taking the mapper's bits straight from the message words
-// in LDS.  Per packet the only HBM traffic is the payload read and the IQ rows written.
-// Dynamic LDS per wave: a_words (MPDU / message words) + 8*RS float2 (scrambled words during
-// encoding, FFT transposition and row staging afterwards).
+// Per packet the only HBM traffic is the payload read and the IQ rows written.  The wavefront
+//   1. scrambles its packet into LDS (scramble_packet),
+//   2. copies the preamble rows and zeroes the gap rows (coalesced stores that drain while the
+//      wave goes on computing),
+//   3. per chunk of up to 64 symbols: builds the symbols' slot rows, one lane per symbol
+//      (SIGNAL: one lane per carrier), then
+//   4. emits the chunk's rows 8 at a time, 8 lanes per symbol: the lane fetches its 8 decimated
+//      carriers straight from the LUT by slot byte and runs ifft64_emit.
+// Dynamic LDS per wave: [0, a_words) natural MPDU, later the slot rows; then 8*RS float2 of FFT
+// transposition / row staging; the scrambled words U live in the staging area when the plan's
+// packets have at most 64 symbols (one chunk: U is dead before the first group), otherwise
+// behind it (u_off).
 
-constexpr int TX_WAVES = 4;
+constexpr int TX_WAVES = 8;
 constexpr int TX_B_WORDS = 8 * RS * 2;
 
 // (second launch bound = 4 waves per SIMD: caps the kernel at 128 VGPRs; uncapped, hipcc spends
@@ -869,85 +1078,152 @@ constexpr int TX_B_WORDS = 8 * RS * 2;
 template <bool UNIFORM, int REGIME>
 __global__ void __launch_bounds__(64 * TX_WAVES, 4)
 k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads, float2 *__restrict__ iq,
-     uint32_t a_words)
+     uint32_t a_words, uint32_t u_off, uint32_t wave_words)
 {
     extern __shared__ __align__(16) uint32_t s_dyn[];
     __shared__ uint32_t s_crc[1024];
     __shared__ uint32_t s_scr[128];
     __shared__ float2 s_lut[LUT_SIZE];
-    __shared__ float2 s_pre[PRE_ROWS * SYM_LEN];
+    __shared__ __align__(16) float2 s_pre[PRE_ROWS * SYM_LEN];
     __shared__ float2 s_tw[64];
+    __shared__ int s_sigc[64];            // SIGNAL row: bin_code of the bin behind row byte i (-1: none)
+    __shared__ uint32_t s_win[8][4];      // per l = lane % 8: slot-row window (see below)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float amp = P.amp;
+    const bool swap_iq = (P.flags & OFDMTX_F_SWAPIQ) != 0;
+    if (tid < 64) s_sigc[tid] = slot_code_of(tid, std::make_integer_sequence<int, 4 * SLOT_ROW_WORDS>{});
+    if (tid < 8) {
+        // lane l's window into a slot row: three words from word seg_off / 4, shifted right by
+        // seg_off % 4 bytes, hold the lane's bins in ascending order; sel_lo / sel_hi (v_perm_b32
+        // selectors) spread them over m = 0..3 / 4..7 and put slot 0 (zero) where bin l + 8m is a null
+        uint32_t sel_lo = 0, sel_hi = 0, seg_off = 0, cnt = 0;
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+            const bool null_bin = bin_code(tid + 8 * m) == -1;
+            const uint32_t sb = null_bin ? 0x0Cu : cnt;
+            cnt += null_bin ? 0u : 1u;
+            if (m < 4) sel_lo |= sb << (8 * m); else sel_hi |= sb << (8 * (m - 4));
+        }
+#pragma unroll
+        for (int ll = 1; ll < 8; ll++) seg_off = tid == ll ? (uint32_t)slot_seg_off(ll) : seg_off;
+        s_win[tid][0] = sel_lo;
+        s_win[tid][1] = sel_hi;
+        s_win[tid][2] = seg_off >> 2;
+        s_win[tid][3] = seg_off & 3u;
+    }
     // 1/sqrt(64) (examples/ftw_ofdm.py:126) is a power of two: (x*0.125)*amp == x*(0.125*amp)
     const float scale = 0.125f * amp;
     for (int i = tid; i < 127; i += 64 * TX_WAVES) s_scr[i] = T.scr_word[i];
     for (int i = tid; i < 1024; i += 64 * TX_WAVES) s_crc[i] = T.crc_tab[i];
     for (int i = tid; i < LUT_SIZE; i += 64 * TX_WAVES) s_lut[i] = T.lut[i];
     for (int i = tid; i < PRE_ROWS * SYM_LEN; i += 64 * TX_WAVES) {
-        float2 v = T.preamble[i];
-        s_pre[i] = make_float2(v.x * amp, v.y * amp);
-    }
+        const float2 v = T.preamble[i];                   // pu:508 literals as float32 times tx_amplitude,
+        s_pre[i] = swap_iq ? make_float2(v.y * amp, v.x * amp) : make_float2(v.x * amp, v.y * amp);
+    }                                                     // I and Q exchanged if asked (examples/ftw_ofdm.py:155-163)
     for (int i = tid; i < 64; i += 64 * TX_WAVES) {
         const float2 w = T.tw64[((i & 7) * (i >> 3)) & 63];
         s_tw[i] = make_float2(w.x * scale, w.y * scale);
     }
     __syncthreads();
 
-    uint32_t *A = s_dyn + (size_t)wave * (a_words + TX_B_WORDS);
-    uint32_t *U = A + a_words;
-    float2 *buf = reinterpret_cast<float2 *>(U);
+    uint32_t *A = s_dyn + (size_t)wave * wave_words;      // natural MPDU, then the slot rows
+    uint32_t *SI = A;
+    v2f *buf = reinterpret_cast<v2f *>(A + a_words);
+    uint32_t *U = A + u_off;
 
-    const int l = lane & 7, g = lane >> 3;
-    uint32_t kinds = 0;
-    int d0 = -1;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int c = bin_code(8 * l + i);
-        if (c >= 0 && d0 < 0) d0 = c;
-        kinds |= (uint32_t)(c >= 0 ? 1 : (c == -1 ? 0 : (c == -2 ? 2 : 3))) << (2 * i);
-    }
     uint64_t pneg_lo = T.pilot_neg[0] | ((uint64_t)T.pilot_neg[1] << 32);
     uint64_t pneg_hi = T.pilot_neg[2] | ((uint64_t)T.pilot_neg[3] << 32);
     asm volatile("" : "+s"(pneg_lo), "+s"(pneg_hi));
 
     const uint32_t pre_rows = (P.flags & OFDMTX_F_PREAMBLE) ? PRE_ROWS : 0;
     const uint32_t gap_rows = (P.flags & OFDMTX_F_ZEROGAP) ? GAP_ROWS : 0;
-    const bool swap_iq = (P.flags & OFDMTX_F_SWAPIQ) != 0;
+    const v2f *lut = reinterpret_cast<const v2f *>(s_lut);
 
     for (uint32_t p = blockIdx.x * TX_WAVES + wave; p < P.n_pkts; p += gridDim.x * TX_WAVES) {
         const Pkt k = load_pkt<UNIFORM>(P, p);
         const RegimeInfo ri = regime_info(REGIME ? REGIME : (int)k.regime);
-        encode_packet<REGIME>(k, ri, T, payloads, A, U, s_crc, s_scr, lane, nullptr, nullptr, nullptr);
-
-        const uint32_t n_rows = pre_rows + 1u + k.n_sym + gap_rows;
         const size_t row0 = UNIFORM ? (size_t)p * P.rows_per_pkt : (size_t)P.row_start[p];
         float4 *out = reinterpret_cast<float4 *>(iq + row0 * SYM_LEN);
-        for (uint32_t r0 = 0; r0 < n_rows; r0 += 8u) {
-            SEC("prep");
-            const uint32_t r = r0 + g;
-            const int type = r >= n_rows ? 3 : (r < pre_rows ? 0 : (r - pre_rows <= k.n_sym ? 1 : 2));
-            uint64_t W = 0;
-            uint32_t nb = 1, lut_off = 0;
-            float pil = 1.f;
-            if (type == 1) {
-                const uint32_t s = r - pre_rows;                         // symbol index, 0 = SIGNAL
-                nb = s == 0 ? 1u : (uint32_t)ri.n_bpsc;                  // ftw/ftw_ofdm_mapper.cc:184-191
-                lut_off = s == 0 ? 0u : (uint32_t)ri.lut_off;
-                // message bit m sits at bit 16 + m of the word stream A[] (A[0] holds 16 spare bits)
-                const uint32_t bit = 16u + (s == 0 ? 0u : 48u + (s - 1u) * ri.n_cbps) + (uint32_t)d0 * nb;
-                const uint32_t w = bit >> 5, sh = bit & 31u;
-                const uint32_t b0 = A[w], b1 = A[w + 1], b2 = A[w + 2];
-                W = ((uint64_t)__funnelshift_l(b1, b0, sh) << 32) | __funnelshift_l(b2, b1, sh);
-                const uint32_t pidx = (k.pilot_base + s) % 127u;         // ftw/ftw_ofdm_pilot_cc.cc:116
-                pil = ((uint32_t)((pidx < 64u ? pneg_lo : pneg_hi) >> (pidx & 63u)) & 1u) ? -1.f : 1.f;
+        const uint32_t sym_rows = k.n_sym + 1u;                    // SIGNAL + DATA symbols
+
+        scramble_packet(k, ri, T, payloads, A, U, s_crc, s_scr, lane, nullptr, nullptr);
+
+        SEC("copy");
+        // ---- preamble rows (ftw/ftw_ofdm_preamble.cc:79-95) and zero gap (ftw/ftw_zerogap.cc:88-99)
+        if (pre_rows) {
+            const float4 *pre4 = reinterpret_cast<const float4 *>(s_pre);
+            for (uint32_t i = lane; i < PRE_ROWS * SYM_LEN / 2; i += 64) out[i] = pre4[i];
+        }
+        if (gap_rows) {
+            float4 *gp = out + (size_t)(pre_rows + sym_rows) * (SYM_LEN / 2);
+            for (uint32_t i = lane; i < GAP_ROWS * SYM_LEN / 2; i += 64) gp[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        out += (size_t)pre_rows * (SYM_LEN / 2);
+
+        for (uint32_t c0 = 0; c0 < sym_rows; c0 += 64u) {
+            SEC("e4_signal");
+            // ---- SIGNAL row: 48 coded bits (N = 48: first permutation only, pu:245-249), BPSK
+            if (c0 == 0) {
+                const uint32_t t = 63u - lane;            // ballot bit `lane` = carrier 63 - lane
+                uint32_t bi = 0;
+                if (t < 48u) bi = coded_bit(U, 16u * (t % 3u) + t / 3u);
+                const unsigned long long mi = __ballot(bi);
+                const uint32_t neg0 = pilot_negative(k.pilot_base % 127u, pneg_lo, pneg_hi);
+                if (lane < 4 * SLOT_ROW_WORDS) {
+                    const int sig_c = s_sigc[lane];
+                    const uint32_t v = sig_c >= 0 ? (uint32_t)LUT_PM1 | ((uint32_t)(mi >> (63 - sig_c)) & 1u)
+                                                  : ((sig_c == -3 ? (uint32_t)LUT_PM1 : LUT_PM1 + 1u) ^ neg0);
+                    reinterpret_cast<uint8_t *>(SI)[lane] = (uint8_t)v;
+                }
             }
-            modulate_group(type, r, W, nb, lut_off, pil, 0u, nullptr, kinds, d0, l, g, lane, buf, s_lut, s_pre,
-                           s_tw, swap_iq, out + (size_t)r0 * (SYM_LEN / 2),
-                           n_rows - r0 < 8u ? n_rows - r0 : 8u);
-            SEC("end");
+            SEC("e5_data");
+            // ---- DATA rows.  REGIME != 0: the batch has one regime, known when the kernel was
+            // chosen, and only that instantiation is compiled in; 0 dispatches per packet.
+            switch (REGIME ? (uint32_t)REGIME : k.regime) {
+            case 1: symbol_slots<1, 0>(U, SI, c0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
+            case 2: symbol_slots<1, 1>(U, SI, c0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
+            case 3: symbol_slots<2, 0>(U, SI, c0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
+            case 4: symbol_slots<2, 1>(U, SI, c0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
+            case 5: symbol_slots<4, 0>(U, SI, c0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
+            case 6: symbol_slots<4, 1>(U, SI, c0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
+            case 7: symbol_slots<6, 2>(U, SI, c0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
+            default: symbol_slots<6, 1>(U, SI, c0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
+            }
             wave_sync();
+
+            // Lane-dependent addressing of the row phase, derived here from an opaque copy of the
+            // lane number: hoisted out of the packet loop these ~25 registers would stay live
+            // through the encoder, whose bit table needs the register file to itself.
+            int lane_r = lane;
+            asm volatile("" : "+v"(lane_r));
+            const int l = lane_r & 7, g = lane_r >> 3;
+            const uint32_t sel_lo = s_win[l][0], sel_hi = s_win[l][1], slot_sh = s_win[l][3];
+            const uint32_t slot_word0 = SLOT_ROW_WORDS * (uint32_t)g + s_win[l][2];
+            const uint32_t rows_chunk = sym_rows - c0 < 64u ? sym_rows - c0 : 64u;
+            for (uint32_t r0 = 0; r0 < rows_chunk; r0 += 8u) {
+                SEC("map");
+                const int type = r0 + (uint32_t)g < rows_chunk ? 1 : 3;
+                v2f x[8];
+                if (type == 1) {
+                    const uint32_t *rp = SI + SLOT_ROW_WORDS * r0 + slot_word0;
+                    const uint32_t d0 = rp[0], d1 = rp[1], d2 = rp[2];
+                    const uint32_t wlo = __builtin_amdgcn_alignbyte(d1, d0, slot_sh);
+                    const uint32_t whi = __builtin_amdgcn_alignbyte(d2, d1, slot_sh);
+                    const uint32_t s_lo = __builtin_amdgcn_perm(whi, wlo, sel_lo);
+                    const uint32_t s_hi = __builtin_amdgcn_perm(whi, wlo, sel_hi);
+#pragma unroll
+                    for (int m = 0; m < 4; m++) {
+                        x[m] = lut[(s_lo >> (8 * m)) & 0xFFu];
+                        x[m + 4] = lut[(s_hi >> (8 * m)) & 0xFFu];
+                    }
+                }
+                ifft64_emit<true>(type, 0u, x, true, l, g, lane_r, buf, nullptr, reinterpret_cast<const v2f *>(s_tw),
+                                  swap_iq, out + (size_t)(c0 + r0) * (SYM_LEN / 2),
+                                  rows_chunk - r0 < 8u ? rows_chunk - r0 : 8u);
+                SEC("end");
+                wave_sync();
+            }
         }
     }
 }
@@ -993,7 +1269,9 @@ struct ofdmtx_plan {
     uint32_t *d_row_start;
     uint32_t *d_group_pkt;
     ofdmtx_pkt_info uni;   // uniform geometry
-    uint32_t tx_a_words;   // LDS words per wave the fused kernel needs for the largest packet
+    uint32_t tx_a_words;   // LDS words per wave the fused kernel needs for the largest packet (first region)
+    uint32_t tx_u_words;   // ... for the scrambled words of the longest packet
+    uint32_t max_sym_rows; // largest n_sym + 1 of the plan
 };
 
 extern "C" {
@@ -1068,8 +1346,12 @@ int ofdmtx_create(int device, ofdmtx_ctx **out)
     HIPCHK(hipMalloc(&c->d_pre, 320 * sizeof(float2)));
     HIPCHK(hipMalloc(&c->d_tw, 64 * sizeof(float2)));
     float lut[2 * LUT_SIZE];
-    lut[0] = -1.f; lut[1] = 0.f; lut[2] = 1.f; lut[3] = 0.f;   // ftw/ftw_ofdm_mapper.cc:179
-    memcpy(lut + 4, OFDMTX_CONST_DEFAULT, sizeof(OFDMTX_CONST_DEFAULT));
+    memset(lut, 0, sizeof(lut));
+    lut[2 * LUT_PM1] = -1.f; lut[2 * LUT_PM1 + 2] = 1.f;        // ftw/ftw_ofdm_mapper.cc:179, pilots
+    memcpy(lut + 2 * 4, OFDMTX_CONST_DEFAULT + 2 * 0, 2 * 2 * sizeof(float));     // BPSK
+    memcpy(lut + 2 * 8, OFDMTX_CONST_DEFAULT + 2 * 2, 2 * 4 * sizeof(float));     // QPSK
+    memcpy(lut + 2 * 16, OFDMTX_CONST_DEFAULT + 2 * 6, 2 * 16 * sizeof(float));   // 16-QAM
+    memcpy(lut + 2 * 64, OFDMTX_CONST_DEFAULT + 2 * 22, 2 * 64 * sizeof(float));  // 64-QAM
     HIPCHK(hipMemcpy(c->d_scr, OFDMTX_SCR_WORD, sizeof(OFDMTX_SCR_WORD), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->d_lut, lut, sizeof(lut), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->d_pre, OFDMTX_PREAMBLE, sizeof(OFDMTX_PREAMBLE), hipMemcpyHostToDevice));
@@ -1118,10 +1400,10 @@ int ofdmtx_set_constellation(ofdmtx_ctx *c, int n_bpsc, const float *re_im, int 
     if (!c || !re_im) return OFDMTX_EINVAL;
     int off;
     switch (n_bpsc) {
-    case 1: off = 2; break;
-    case 2: off = 4; break;
-    case 4: off = 8; break;
-    case 6: off = 24; break;
+    case 1: off = 4; break;
+    case 2: off = 8; break;
+    case 4: off = 16; break;
+    case 6: off = 64; break;
     default: return OFDMTX_EINVAL;
     }
     if (n != (1 << n_bpsc)) return OFDMTX_EINVAL;
@@ -1132,14 +1414,20 @@ int ofdmtx_set_constellation(ofdmtx_ctx *c, int n_bpsc, const float *re_im, int 
 
 static inline uint32_t align16(uint32_t v) { return (v + 15u) & ~15u; }
 
-// LDS words k_tx needs per wave for a packet: natural MPDU (2 + n_words + 1) or message words
-// (2 SIGNAL + DATA + 3 spare), whichever is larger, rounded to 16 bytes
+// LDS words k_tx needs per wave for a packet: first region = natural MPDU (2 + n_words + 1) or
+// the slot rows of one chunk (+3 words read past the last row's window), whichever is larger;
+// u = the scrambled words (n_words + 2)
 static inline uint32_t tx_words_for(const ofdmtx_pkt_info &pi)
 {
-    uint32_t d = (uint32_t)(pi.plcp_len + 3) / 4 + 4;
-    uint32_t m = 2 + (uint32_t)(pi.n_sym * pi.n_cbps + 31) / 32 + 3;
-    uint32_t w = d > m ? d : m;
+    const uint32_t d = (uint32_t)(pi.plcp_len + 3) / 4 + 4;
+    const uint32_t rows = (uint32_t)pi.n_sym + 1 < 64u ? (uint32_t)pi.n_sym + 1 : 64u;
+    const uint32_t m = rows * SLOT_ROW_WORDS + 3;
+    const uint32_t w = d > m ? d : m;
     return (w + 3u) & ~3u;
+}
+static inline uint32_t tx_u_words_for(const ofdmtx_pkt_info &pi)
+{
+    return (((uint32_t)(pi.plcp_len + 3) / 4 + 4) + 3u) & ~3u;
 }
 
 static void plan_common(ofdmtx_plan *pl, ofdmtx_ctx *ctx, uint64_t n, int pilot_mode,
@@ -1189,6 +1477,8 @@ int ofdmtx_plan_uniform(ofdmtx_ctx *ctx, uint64_t n_pkts, int regime, uint32_t p
     pp.total_rows = (uint32_t)(n_pkts * (uint64_t)pi.n_rows);
     pl->uni = pi;
     pl->tx_a_words = tx_words_for(pi);
+    pl->tx_u_words = tx_u_words_for(pi);
+    pl->max_sym_rows = (uint32_t)pi.n_sym + 1;
     ofdmtx_plan_sizes &sz = pl->sizes;
     sz.n_pkts = n_pkts;
     sz.payload_bytes = n_pkts ? (n_pkts - 1) * payload_stride + payload_len : 0;
@@ -1217,6 +1507,8 @@ int ofdmtx_plan_ragged(ofdmtx_ctx *ctx, uint64_t n_pkts, const uint8_t *regimes,
     PlanParams &pp = pl->pp;
     pp.uniform = 0;
     pl->tx_a_words = 16;
+    pl->tx_u_words = 16;
+    pl->max_sym_rows = 1;
     pl->recs.resize(n_pkts);
     pl->row_start.resize(n_pkts + 1);
     pl->plcp_len.resize(n_pkts);
@@ -1233,6 +1525,8 @@ int ofdmtx_plan_ragged(ofdmtx_ctx *ctx, uint64_t n_pkts, const uint8_t *regimes,
             return rc;
         }
         if (tx_words_for(pi) > pl->tx_a_words) pl->tx_a_words = tx_words_for(pi);
+        if (tx_u_words_for(pi) > pl->tx_u_words) pl->tx_u_words = tx_u_words_for(pi);
+        if ((uint32_t)pi.n_sym + 1 > pl->max_sym_rows) pl->max_sym_rows = (uint32_t)pi.n_sym + 1;
         PktRec &r = pl->recs[i];
         memset(&r, 0, sizeof(r));
         r.pay_off = payload_off ? payload_off[i] : pay;
@@ -1426,16 +1720,25 @@ int ofdmtx_tx(ofdmtx_ctx *ctx, const ofdmtx_plan *pl, const uint8_t *d_payloads,
     if (!d_payloads && pl->sizes.payload_bytes) return OFDMTX_EINVAL;
     if (pl->pp.n_pkts == 0) return OFDMTX_OK;
     HIPCHK(hipSetDevice(ctx->device));
-    const int grid = grid_for(ctx, pl->pp.n_pkts, TX_WAVES, 8);
-    const size_t lds = (size_t)TX_WAVES * (pl->tx_a_words + TX_B_WORDS) * sizeof(uint32_t);
+    // one chunk: U shares the staging area; several chunks: U needs a region of its own
+    const bool one_chunk = pl->max_sym_rows <= 64u;
+    const uint32_t a_words = pl->tx_a_words;
+    const uint32_t u_off = one_chunk ? a_words : a_words + (uint32_t)TX_B_WORDS;
+    const uint32_t wave_words = a_words + (uint32_t)TX_B_WORDS + (one_chunk ? 0u : pl->tx_u_words);
+    const size_t lds = (size_t)TX_WAVES * wave_words * sizeof(uint32_t);
+    const int grid = grid_for(ctx, pl->pp.n_pkts, TX_WAVES, 2);
     hipStream_t st = (hipStream_t)stream;
     const PlanParams &pp = pl->pp;
     const DevTables tab = ctx->tables();
     float2 *iq = reinterpret_cast<float2 *>(d_iq);
-    const uint32_t a_words = pl->tx_a_words;
+    // a workgroup may use more than the default 64 KiB of LDS only after asking for it
 #define LAUNCH_TX(U_, R_)                                                                            \
-    hipLaunchKernelGGL((k_tx<U_, R_>), dim3(grid), dim3(64 * TX_WAVES), lds, st, pp, tab, d_payloads, \
-                       iq, a_words)
+    do {                                                                                             \
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tx<U_, R_>),                    \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));           \
+        hipLaunchKernelGGL((k_tx<U_, R_>), dim3(grid), dim3(64 * TX_WAVES), lds, st, pp, tab,        \
+                           d_payloads, iq, a_words, u_off, wave_words);                              \
+    } while (0)
     if (!pp.uniform) {
         LAUNCH_TX(false, 0);
     } else {
