@@ -140,10 +140,70 @@ int ofdmtx_encode_bits(ofdmtx_ctx *ctx, const ofdmtx_plan *plan, const uint8_t *
 int ofdmtx_modulate(ofdmtx_ctx *ctx, const ofdmtx_plan *plan, const uint8_t *d_msg,
                     float *d_mapped, float *d_iq, void *stream);
 
-/* payload -> IQ for the whole batch (send_pkt + flowgraph).  d_work: scratch of
- * ofdmtx_plan_sizes.msg_bytes bytes. */
+/* payload -> IQ for the whole batch (send_pkt + flowgraph) in one fused kernel.  d_work is
+ * not used any more (the mapper messages stay in LDS) and may be NULL. */
 int ofdmtx_tx(ofdmtx_ctx *ctx, const ofdmtx_plan *plan, const uint8_t *d_payloads,
               uint8_t *d_work, float *d_iq, void *stream);
+
+/* ---- single-message stage operators ---------------------------------------------------
+ * The per-packet functions of examples/ftw_packet_utils.py, each on ONE byte string in device
+ * memory (MSB-first bits), for callers that keep the reference's stage-by-stage call sequence
+ * (examples/ftw_ofdm.py:207-214).  Batches belong to ofdmtx_encode_bits / ofdmtx_tx. */
+/* scrambler(pkt, Length_data), examples/ftw_packet_utils.py:344-367.  d_out: n_bytes.
+ * OFDMTX_EINVAL if the six tail bits at 40 + 8*length_data lie outside the string (the
+ * reference raises IndexError). */
+int ofdmtx_scramble(ofdmtx_ctx *ctx, const uint8_t *d_in, uint32_t n_bytes, uint32_t length_data,
+                    uint8_t *d_out, void *stream);
+/* conv_encoder(pkt, Length, regime, N_cbps, N_bpsc, N_sym, N_rate),
+ * examples/ftw_packet_utils.py:280-341.  d_out: 6 + n_sym*N_cbps/8 bytes.  OFDMTX_EINVAL if
+ * the input is too short to yield that many punctured bits. */
+int ofdmtx_conv_encode(ofdmtx_ctx *ctx, const uint8_t *d_in, uint32_t n_bytes, int regime,
+                       uint32_t n_sym, uint8_t *d_out, void *stream);
+/* interleaver(payload, regime, N_cbps, N_bpsc), examples/ftw_packet_utils.py:222-277.
+ * n_bytes = 6 + k*N_cbps/8 (whole symbols); d_out: n_bytes. */
+int ofdmtx_interleave(ofdmtx_ctx *ctx, const uint8_t *d_in, uint32_t n_bytes, int regime,
+                      uint8_t *d_out, void *stream);
+
+/* ---- variable-size modulator (rawofdm) --------------------------------------------------
+ * Stands in for raw.ofdm_mapper (rawofdm/src/lib/ofdm/raw_ofdm.i:18-20,
+ * rawofdm/src/lib/ofdm/raw_ofdm_mapper.cc:22-80) and the GNU Radio blocks wired behind it in
+ * rawofdm/src/python/raw_ofdm_mod.py:44-52: digital.ofdm_insert_preamble, gr.fft_vcc(N, False,
+ * [], True), digital.ofdm_cyclic_prefixer(N, N + cp), gr.multiply_const_cc(1/sqrt(N)).
+ *
+ * carrier_map[fft_length]: 0 unused, 1 data, 2 pilot, DC in the middle (padded_carriers of
+ * rawofdm/src/python/raw_ofdm_params.py:77-93); any other value -> OFDMTX_ESHAPE (the reference
+ * throws std::invalid_argument, raw_ofdm_mapper.cc:37-38).  preambles: n_pre frequency-domain
+ * symbols of fft_length complex values (re,im float pairs; padded_preambles of
+ * raw_ofdm_params.py:60-75), host memory.  fft_length must be 64, 128, 256, 512 or 1024
+ * (OFDMTX_ESHAPE otherwise).  Output rows have fft_length + cp_length samples. */
+typedef struct ofdmtx_raw_plan ofdmtx_raw_plan;
+typedef struct ofdmtx_raw_sizes {
+    uint32_t fft_length, cp_length;
+    uint32_t data_tones;      /* carriers marked 1: complex values consumed per data symbol  */
+    uint32_t n_pre;           /* preamble symbols emitted in front of every frame            */
+    uint64_t n_sym;           /* data symbols the plan reads                                 */
+    uint64_t n_frames;
+    uint64_t n_rows;          /* output rows = symbols written (preambles + kept data)       */
+    uint64_t n_samples;       /* n_rows * (fft_length + cp_length) complex64                 */
+} ofdmtx_raw_sizes;
+/* n_frames frames of frame_size data symbols each, every frame starting with its flag set
+ * (rawofdm/examples/ofdm_rxtx.py:81-87): no per-symbol table is needed. */
+int ofdmtx_raw_plan_frames(ofdmtx_ctx *ctx, uint32_t fft_length, uint32_t cp_length,
+                           const int32_t *carrier_map, const float *preambles, uint32_t n_pre,
+                           uint64_t n_frames, uint32_t frame_size, ofdmtx_raw_plan **out);
+/* General form: flags[n_sym] (host) is the start-of-frame input of ofdm_mod
+ * (raw_ofdm_mod.py:25,51): a set flag emits the preamble symbols before that data symbol;
+ * data symbols in front of the first set flag are dropped. */
+int ofdmtx_raw_plan_flags(ofdmtx_ctx *ctx, uint32_t fft_length, uint32_t cp_length,
+                          const int32_t *carrier_map, const float *preambles, uint32_t n_pre,
+                          const uint8_t *flags, uint64_t n_sym, ofdmtx_raw_plan **out);
+int ofdmtx_raw_plan_destroy(ofdmtx_raw_plan *plan);
+int ofdmtx_raw_plan_get_sizes(const ofdmtx_raw_plan *plan, ofdmtx_raw_sizes *out);
+/* d_data: n_sym x data_tones complex64.  d_mapped (optional tap, may be NULL): n_sym x
+ * fft_length complex64, the mapper block's output ("tx-map.dat", raw_ofdm_mod.py:55-57).
+ * d_iq: n_samples complex64. */
+int ofdmtx_raw_modulate(ofdmtx_ctx *ctx, const ofdmtx_raw_plan *plan, const float *d_data,
+                        float *d_mapped, float *d_iq, void *stream);
 
 #ifdef __cplusplus
 }

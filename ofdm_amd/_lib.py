@@ -32,6 +32,11 @@ class PlanSizes(C.Structure):
                                            "n_symbols", "n_rows", "n_samples")]
 
 
+class RawSizes(C.Structure):
+    _fields_ = ([(n, C.c_uint32) for n in ("fft_length", "cp_length", "data_tones", "n_pre")] +
+                [(n, C.c_uint64) for n in ("n_sym", "n_frames", "n_rows", "n_samples")])
+
+
 # name -> (restype, argtypes); must list every function include/ofdmtx.h declares
 _VP = C.c_void_p
 PROTOTYPES = {
@@ -52,6 +57,16 @@ PROTOTYPES = {
     "ofdmtx_encode_bits": (C.c_int, [_VP] * 8),
     "ofdmtx_modulate": (C.c_int, [_VP] * 6),
     "ofdmtx_tx": (C.c_int, [_VP] * 6),
+    "ofdmtx_scramble": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, _VP, _VP]),
+    "ofdmtx_conv_encode": (C.c_int, [_VP, _VP, C.c_uint32, C.c_int, C.c_uint32, _VP, _VP]),
+    "ofdmtx_interleave": (C.c_int, [_VP, _VP, C.c_uint32, C.c_int, _VP, _VP]),
+    "ofdmtx_raw_plan_frames": (C.c_int, [_VP, C.c_uint32, C.c_uint32, _VP, _VP, C.c_uint32, C.c_uint64,
+                                         C.c_uint32, C.POINTER(_VP)]),
+    "ofdmtx_raw_plan_flags": (C.c_int, [_VP, C.c_uint32, C.c_uint32, _VP, _VP, C.c_uint32, _VP, C.c_uint64,
+                                        C.POINTER(_VP)]),
+    "ofdmtx_raw_plan_destroy": (C.c_int, [_VP]),
+    "ofdmtx_raw_plan_get_sizes": (C.c_int, [_VP, C.POINTER(RawSizes)]),
+    "ofdmtx_raw_modulate": (C.c_int, [_VP] * 6),
 }
 
 _lib = None

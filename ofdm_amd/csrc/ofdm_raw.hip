@@ -1,0 +1,459 @@
+// libofdmtx, variable-size OFDM modulator (the rawofdm transmit chain): carrier map -> N-point
+// inverse FFT with the DC bin in the middle of the input -> cyclic prefix -> 1/sqrt(N), with the
+// frame preambles inserted.  N = L x M is split into two in-register transforms with one LDS
+// transposition: max(L, M) lanes work on one OFDM symbol.
+//
+// Reference behaviour restated here is cited as file:line relative to the reference root.
+
+#include <math.h>
+#include <string.h>
+
+#include <new>
+#include <utility>
+#include <vector>
+
+#include "ofdm_common.h"
+
+namespace {
+
+constexpr uint32_t ROW_DROPPED = 0xFFFFFFFFu;
+
+// Passed by value to the kernel.
+struct RawParams {
+    uint32_t n, cp, data_tones, n_pre;   // FFT length, cyclic prefix, data carriers per symbol, preamble symbols per frame
+    uint32_t n_sym;                      // data symbols of the batch
+    uint32_t n_frames;                   // frames whose preamble rows are copied in
+    uint32_t frame_size;                 // uniform frames: data symbols per frame; 0: use the tables below
+    const uint32_t *sym_row;             // output row of every data symbol (ROW_DROPPED: none)
+    const uint32_t *frame_row;           // first preamble row of every frame
+    const int16_t *src;                  // per FFT bin k: >= 0 index into the symbol's data, -1 zero, -2 (+1,0), -3 (-1,0)
+    const float2 *tw;                    // e^{+j 2 pi i / N} / sqrt(N), i = 0 .. N-1
+    const float2 *pre_rows;              // n_pre rows of n + cp time-domain samples
+};
+
+// e^{+j 2 pi k / 32}, k = 0 .. 15
+__device__ constexpr float W32C[16] = {1.f, 0.98078528f, 0.923879533f, 0.831469612f, 0.707106781f, 0.555570233f,
+                                       0.382683432f, 0.195090322f, 0.f, -0.195090322f, -0.382683432f, -0.555570233f,
+                                       -0.707106781f, -0.831469612f, -0.923879533f, -0.98078528f};
+__device__ constexpr float W32S[16] = {0.f, 0.195090322f, 0.382683432f, 0.555570233f, 0.707106781f, 0.831469612f,
+                                       0.923879533f, 0.98078528f, 1.f, 0.98078528f, 0.923879533f, 0.831469612f,
+                                       0.707106781f, 0.555570233f, 0.382683432f, 0.195090322f};
+
+// a * w for a wave-uniform w (kept in a scalar register pair)
+__device__ __forceinline__ v2f cmul_s(v2f a, v2f w)
+{
+    v2f t, d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "s"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(d) : "v"(a), "s"(w), "v"(t));
+    return d;
+}
+
+// (a, b) <- (a + w b, a - w b), w = e^{+j 2 pi T / 32}
+template <int T>
+__device__ __forceinline__ void butterfly(v2f &a, v2f &b)
+{
+    const v2f t = a;
+    if constexpr (T == 0) {
+        a = t + b;
+        b = t - b;
+    } else if constexpr (T == 8) {
+        a = add_j(t, b);
+        b = sub_j(t, b);
+    } else {
+        const v2f w = cmul_s(b, (v2f){W32C[T], W32S[T]});
+        a = t + w;
+        b = t - w;
+    }
+}
+
+template <int R, int LEN, int I>
+__device__ __forceinline__ void butterfly_at(v2f (&x)[R])
+{
+    constexpr int half = LEN / 2, base = (I / half) * LEN, k = I % half;
+    butterfly<k * (32 / LEN)>(x[base + k], x[base + k + half]);
+}
+
+template <int R, int LEN, int... I>
+__device__ __forceinline__ void dit_stage(v2f (&x)[R], std::integer_sequence<int, I...>)
+{
+    (butterfly_at<R, LEN, I>(x), ...);
+}
+
+// In-register inverse DFT of R = 8, 16 or 32 points, decimation in time: x holds the input in
+// bit-reversed order on entry and y[p] = sum_m in[m] e^{+j 2 pi m p / R} in natural order on exit.
+template <int R>
+__device__ __forceinline__ void idft_reg(v2f (&x)[R])
+{
+    using half_seq = std::make_integer_sequence<int, R / 2>;
+    dit_stage<R, 2>(x, half_seq{});
+    dit_stage<R, 4>(x, half_seq{});
+    dit_stage<R, 8>(x, half_seq{});
+    if constexpr (R >= 16) dit_stage<R, 16>(x, half_seq{});
+    if constexpr (R >= 32) dit_stage<R, 32>(x, half_seq{});
+}
+
+constexpr int bit_reverse(int i, int n)
+{
+    int r = 0;
+    for (int b = 1; b < n; b <<= 1) {
+        r = (r << 1) | (i & 1);
+        i >>= 1;
+    }
+    return r;
+}
+
+constexpr int RAW_WAVES = 4;
+
+// One work item per wavefront and iteration: either 64 / max(L, M) OFDM symbols (items
+// 0 .. n_groups-1) or the copy of one frame's preamble rows (the items after those).
+//   bin k = l + L m of the (DC-centred) input:  x[M q + p] = sum_l W_L^{l q} W_N^{l p} sum_m X[l + L m] W_M^{m p}
+// step 1: lane l < L transforms its M bins in registers, applies W_N^{l p} / sqrt(N) and writes
+// to LDS; step 2: lane p < M reads the L partial results and transforms them; samples M q + p of
+// one q are contiguous over the lanes p, so the rows are stored straight from registers.
+template <int L, int M>
+__global__ void __launch_bounds__(64 * RAW_WAVES)
+k_raw_modulate(RawParams R, const float2 *__restrict__ data, float2 *__restrict__ mapped, float2 *__restrict__ iq)
+{
+    constexpr int N = L * M, S = L > M ? L : M, SPW = 64 / S;
+    constexpr int TS = M * (L + 1);                       // float2 per symbol in the transposition area (rows padded by 1)
+    extern __shared__ __align__(16) unsigned char s_raw[];
+    v2f *s_tw = reinterpret_cast<v2f *>(s_raw);                            // N
+    v2f *s_t = s_tw + N;                                                   // RAW_WAVES * SPW * TS
+    int16_t *s_src = reinterpret_cast<int16_t *>(s_t + RAW_WAVES * SPW * TS);   // N
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < N; i += 64 * RAW_WAVES) {
+        const float2 w = R.tw[i];
+        s_tw[i] = (v2f){w.x, w.y};
+        s_src[i] = R.src[i];
+    }
+    __syncthreads();
+
+    const int t = lane % S, slot = lane / S;
+    v2f *T = s_t + (wave * SPW + slot) * TS;
+    const uint32_t row_len = R.n + R.cp;
+    const uint32_t n_groups = (R.n_sym + SPW - 1) / SPW;
+    const uint32_t n_items = n_groups + R.n_frames;
+
+    for (uint32_t item = blockIdx.x * RAW_WAVES + wave; item < n_items; item += gridDim.x * RAW_WAVES) {
+        if (item >= n_groups) {
+            // ---- preamble rows of one frame: time-domain table -> output
+            // (gr-digital ofdm_insert_preamble as wired at rawofdm/src/python/raw_ofdm_mod.py:45,50-52)
+            const uint32_t f = item - n_groups;
+            const size_t row = R.frame_size ? (size_t)f * (R.frame_size + R.n_pre) : (size_t)R.frame_row[f];
+            const uint32_t cnt = R.n_pre * row_len;
+            if ((row_len & 1u) == 0u) {
+                const float4 *src4 = reinterpret_cast<const float4 *>(R.pre_rows);
+                float4 *dst4 = reinterpret_cast<float4 *>(iq + row * row_len);
+                for (uint32_t i = lane; i < cnt / 2; i += 64) dst4[i] = src4[i];
+            } else {
+                float2 *dst = iq + row * row_len;
+                for (uint32_t i = lane; i < cnt; i += 64) dst[i] = R.pre_rows[i];
+            }
+            continue;
+        }
+        const uint32_t sym = item * SPW + slot;
+        const bool active = sym < R.n_sym;
+        uint32_t row = ROW_DROPPED;
+        if (active)
+            row = R.frame_size ? (sym / R.frame_size) * (R.frame_size + R.n_pre) + R.n_pre + sym % R.frame_size
+                               : R.sym_row[sym];
+
+        // ---- step 1: carrier map (rawofdm/src/lib/ofdm/raw_ofdm_mapper.cc:53-78) and M-point transforms
+        if (active && t < L) {
+            v2f x[M];
+            const float2 *dsym = data + (size_t)sym * R.data_tones;
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                const int k = t + L * m;
+                const int code = s_src[k];
+                const float2 d = dsym[code >= 0 ? code : 0];
+                v2f v = {d.x, d.y};
+                if (code < 0) v = (v2f){code == -2 ? 1.f : (code == -3 ? -1.f : 0.f), 0.f};
+                if (mapped) mapped[(size_t)sym * N + ((k + N / 2) & (N - 1))] = make_float2(v.x, v.y);
+                x[bit_reverse(m, M)] = v;
+            }
+            idft_reg<M>(x);
+#pragma unroll
+            for (int p = 0; p < M; p++) T[p * (L + 1) + t] = cmul(x[p], s_tw[(t * p) & (N - 1)]);
+        }
+        wave_sync();
+
+        // ---- step 2: L-point transforms, cyclic prefix (gr-digital ofdm_cyclic_prefixer,
+        // rawofdm/src/python/raw_ofdm_mod.py:47) and stores
+        if (active && t < M) {
+            v2f y[L];
+#pragma unroll
+            for (int l = 0; l < L; l++) y[bit_reverse(l, L)] = T[t * (L + 1) + l];
+            idft_reg<L>(y);
+            if (row != ROW_DROPPED) {
+                float2 *o = iq + (size_t)row * row_len;
+                const uint32_t tail = R.n - R.cp;             // samples >= tail are repeated in front
+#pragma unroll
+                for (int q = 0; q < L; q++) {
+                    const uint32_t n = (uint32_t)(M * q + t);
+                    const float2 v = make_float2(y[q].x, y[q].y);
+                    o[R.cp + n] = v;
+                    if (n >= tail) o[n - tail] = v;
+                }
+            }
+        }
+        wave_sync();
+    }
+}
+
+template <int L, int M>
+size_t raw_lds_bytes()
+{
+    constexpr int N = L * M, S = L > M ? L : M, SPW = 64 / S, TS = M * (L + 1);
+    return (size_t)N * sizeof(float2) + (size_t)RAW_WAVES * SPW * TS * sizeof(float2) + (size_t)N * sizeof(int16_t);
+}
+
+template <int L, int M>
+int launch_raw(const ofdmtx_ctx *ctx, const RawParams &rp, const float2 *data, float2 *mapped, float2 *iq,
+               hipStream_t st)
+{
+    constexpr int S = L > M ? L : M, SPW = 64 / S;
+    const size_t lds = raw_lds_bytes<L, M>();
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_raw_modulate<L, M>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const uint64_t items = ((uint64_t)rp.n_sym + SPW - 1) / SPW + rp.n_frames;
+    uint64_t blocks = (items + RAW_WAVES - 1) / RAW_WAVES;
+    const uint64_t per_cu = 160u * 1024u / lds ? 160u * 1024u / lds : 1;
+    const uint64_t cap = (uint64_t)ctx->n_cu * (per_cu < 8 ? per_cu : 8);
+    if (blocks > cap) blocks = cap;
+    if (blocks == 0) return OFDMTX_OK;
+    hipLaunchKernelGGL((k_raw_modulate<L, M>), dim3((unsigned)blocks), dim3(64 * RAW_WAVES), lds, st, rp, data,
+                       mapped, iq);
+    HIPCHK(hipGetLastError());
+    return OFDMTX_OK;
+}
+
+int launch_raw_n(const ofdmtx_ctx *ctx, const RawParams &rp, const float2 *data, float2 *mapped, float2 *iq,
+                 hipStream_t st)
+{
+    switch (rp.n) {
+    case 64: return launch_raw<8, 8>(ctx, rp, data, mapped, iq, st);
+    case 128: return launch_raw<8, 16>(ctx, rp, data, mapped, iq, st);
+    case 256: return launch_raw<16, 16>(ctx, rp, data, mapped, iq, st);
+    case 512: return launch_raw<16, 32>(ctx, rp, data, mapped, iq, st);
+    case 1024: return launch_raw<32, 32>(ctx, rp, data, mapped, iq, st);
+    default: return OFDMTX_ESHAPE;
+    }
+}
+
+}  // namespace
+
+struct ofdmtx_raw_plan {
+    ofdmtx_ctx *ctx;
+    RawParams rp;
+    ofdmtx_raw_sizes sizes;
+    int16_t *d_src;
+    float2 *d_tw;
+    float2 *d_pre_rows;
+    uint32_t *d_sym_row;
+    uint32_t *d_frame_row;
+};
+
+namespace {
+
+// Tables shared by both plan flavours; transforms the preamble symbols once.
+int raw_plan_common(ofdmtx_ctx *ctx, uint32_t n, uint32_t cp, const int32_t *carrier_map, const float *preambles,
+                    uint32_t n_pre, ofdmtx_raw_plan **out)
+{
+    if (!ctx || !out || !carrier_map || (n_pre && !preambles)) return OFDMTX_EINVAL;
+    *out = nullptr;
+    if (n != 64 && n != 128 && n != 256 && n != 512 && n != 1024) return OFDMTX_ESHAPE;
+    if (cp > n) return OFDMTX_EINVAL;
+    // rawofdm/src/lib/ofdm/raw_ofdm_mapper.cc:32-40: data carriers and pilots in index order;
+    // :62-66 pilots alternate +1, -1, ... over the pilot carriers, the same in every symbol
+    std::vector<int16_t> code(n), src(n);
+    uint32_t n_data = 0, n_pil = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        switch (carrier_map[i]) {
+        case 0: code[i] = -1; break;
+        case 1: code[i] = (int16_t)n_data++; break;
+        case 2: code[i] = (n_pil++ & 1u) ? -3 : -2; break;
+        default: return OFDMTX_ESHAPE;          // "carrier_map must include only 0,1,2"
+        }
+    }
+    // gr.fft_vcc(N, False, [], True) (rawofdm/src/python/raw_ofdm_mod.py:46): the transform's bin k
+    // is input element (k + N/2) mod N
+    for (uint32_t k = 0; k < n; k++) src[k] = code[(k + n / 2) % n];
+    std::vector<float2> tw(n);
+    const double scale = (double)(float)(1.0 / sqrt((double)n));       // raw_ofdm_mod.py:48, a float32 constant
+    for (uint32_t i = 0; i < n; i++) {
+        const double a = 2.0 * M_PI * (double)i / (double)n;
+        tw[i] = make_float2((float)(cos(a) * scale), (float)(sin(a) * scale));
+    }
+
+    ofdmtx_raw_plan *pl = new (std::nothrow) ofdmtx_raw_plan();
+    if (!pl) return OFDMTX_ENOMEM;
+    memset(pl, 0, sizeof(*pl));
+    pl->ctx = ctx;
+    RawParams &rp = pl->rp;
+    rp.n = n;
+    rp.cp = cp;
+    rp.data_tones = n_data;
+    rp.n_pre = n_pre;
+    const uint32_t row_len = n + cp;
+    int16_t *d_ident = nullptr;
+    float2 *d_freq = nullptr;
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e == hipSuccess) e = hipMalloc(&pl->d_src, n * sizeof(int16_t));
+    if (e == hipSuccess) e = hipMalloc(&pl->d_tw, n * sizeof(float2));
+    if (e == hipSuccess) e = hipMalloc(&pl->d_pre_rows, (size_t)(n_pre ? n_pre : 1) * row_len * sizeof(float2));
+    if (e == hipSuccess) e = hipMemcpy(pl->d_src, src.data(), n * sizeof(int16_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(pl->d_tw, tw.data(), n * sizeof(float2), hipMemcpyHostToDevice);
+    int rc = OFDMTX_OK;
+    if (e == hipSuccess && n_pre) {
+        // the preamble symbols are full N-bin vectors: run them through the same kernel with an
+        // identity carrier map (every bin a "data" carrier)
+        std::vector<int16_t> ident(n);
+        for (uint32_t k = 0; k < n; k++) ident[k] = (int16_t)((k + n / 2) % n);
+        e = hipMalloc(&d_ident, n * sizeof(int16_t));
+        if (e == hipSuccess) e = hipMalloc(&d_freq, (size_t)n_pre * n * sizeof(float2));
+        if (e == hipSuccess) e = hipMemcpy(d_ident, ident.data(), n * sizeof(int16_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess)
+            e = hipMemcpy(d_freq, preambles, (size_t)n_pre * n * sizeof(float2), hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            RawParams pp = rp;
+            pp.data_tones = n;
+            pp.n_pre = 0;
+            pp.n_sym = n_pre;
+            pp.n_frames = 0;
+            pp.frame_size = n_pre;              // row = symbol index
+            pp.src = d_ident;
+            pp.tw = pl->d_tw;
+            rc = launch_raw_n(ctx, pp, d_freq, nullptr, pl->d_pre_rows, nullptr);
+            if (rc == OFDMTX_OK) e = hipDeviceSynchronize();
+        }
+    }
+    if (d_ident) (void)hipFree(d_ident);
+    if (d_freq) (void)hipFree(d_freq);
+    if (e != hipSuccess || rc != OFDMTX_OK) {
+        if (e != hipSuccess) {
+            ofdmtx_g_last_hip = (int)e;
+            rc = OFDMTX_EHIP;
+        }
+        ofdmtx_raw_plan_destroy(pl);
+        return rc;
+    }
+    rp.src = pl->d_src;
+    rp.tw = pl->d_tw;
+    rp.pre_rows = pl->d_pre_rows;
+    pl->sizes.fft_length = n;
+    pl->sizes.cp_length = cp;
+    pl->sizes.data_tones = n_data;
+    pl->sizes.n_pre = n_pre;
+    *out = pl;
+    return OFDMTX_OK;
+}
+
+void raw_finish_sizes(ofdmtx_raw_plan *pl, uint64_t n_sym, uint64_t n_frames, uint64_t n_rows)
+{
+    pl->sizes.n_sym = n_sym;
+    pl->sizes.n_frames = n_frames;
+    pl->sizes.n_rows = n_rows;
+    pl->sizes.n_samples = n_rows * (pl->rp.n + pl->rp.cp);
+}
+
+}  // namespace
+
+extern "C" {
+
+int ofdmtx_raw_plan_frames(ofdmtx_ctx *ctx, uint32_t fft_length, uint32_t cp_length, const int32_t *carrier_map,
+                           const float *preambles, uint32_t n_pre, uint64_t n_frames, uint32_t frame_size,
+                           ofdmtx_raw_plan **out)
+{
+    if (frame_size == 0) return OFDMTX_EINVAL;
+    const uint64_t n_sym = n_frames * frame_size, n_rows = n_frames * ((uint64_t)frame_size + n_pre);
+    if (n_rows >= 0xFFFFFFF0ull) return OFDMTX_ETOOBIG;
+    ofdmtx_raw_plan *pl;
+    int rc = raw_plan_common(ctx, fft_length, cp_length, carrier_map, preambles, n_pre, &pl);
+    if (rc) return rc;
+    pl->rp.n_sym = (uint32_t)n_sym;
+    pl->rp.n_frames = n_pre ? (uint32_t)n_frames : 0;
+    pl->rp.frame_size = frame_size;
+    raw_finish_sizes(pl, n_sym, n_frames, n_rows);
+    *out = pl;
+    return OFDMTX_OK;
+}
+
+int ofdmtx_raw_plan_flags(ofdmtx_ctx *ctx, uint32_t fft_length, uint32_t cp_length, const int32_t *carrier_map,
+                          const float *preambles, uint32_t n_pre, const uint8_t *flags, uint64_t n_sym,
+                          ofdmtx_raw_plan **out)
+{
+    if (n_sym && !flags) return OFDMTX_EINVAL;
+    if (n_sym * ((uint64_t)n_pre + 1) >= 0xFFFFFFF0ull) return OFDMTX_ETOOBIG;
+    ofdmtx_raw_plan *pl;
+    int rc = raw_plan_common(ctx, fft_length, cp_length, carrier_map, preambles, n_pre, &pl);
+    if (rc) return rc;
+    // symbols in front of the first flagged one are dropped; a flagged symbol is preceded by
+    // every preamble symbol
+    std::vector<uint32_t> sym_row(n_sym ? n_sym : 1), frame_row;
+    uint64_t row = 0;
+    bool started = false;
+    for (uint64_t j = 0; j < n_sym; j++) {
+        if (flags[j] & 1u) {
+            started = true;
+            frame_row.push_back((uint32_t)row);
+            row += n_pre;
+        }
+        sym_row[j] = started ? (uint32_t)row++ : ROW_DROPPED;
+    }
+    const size_t nf = frame_row.size();
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e == hipSuccess) e = hipMalloc(&pl->d_sym_row, sym_row.size() * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&pl->d_frame_row, (nf ? nf : 1) * sizeof(uint32_t));
+    if (e == hipSuccess)
+        e = hipMemcpy(pl->d_sym_row, sym_row.data(), sym_row.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess && nf)
+        e = hipMemcpy(pl->d_frame_row, frame_row.data(), nf * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        ofdmtx_g_last_hip = (int)e;
+        ofdmtx_raw_plan_destroy(pl);
+        return OFDMTX_EHIP;
+    }
+    pl->rp.n_sym = (uint32_t)n_sym;
+    pl->rp.n_frames = n_pre ? (uint32_t)nf : 0;
+    pl->rp.frame_size = 0;
+    pl->rp.sym_row = pl->d_sym_row;
+    pl->rp.frame_row = pl->d_frame_row;
+    raw_finish_sizes(pl, n_sym, nf, row);
+    *out = pl;
+    return OFDMTX_OK;
+}
+
+int ofdmtx_raw_plan_destroy(ofdmtx_raw_plan *pl)
+{
+    if (!pl) return OFDMTX_EINVAL;
+    (void)hipSetDevice(pl->ctx->device);
+    if (pl->d_src) (void)hipFree(pl->d_src);
+    if (pl->d_tw) (void)hipFree(pl->d_tw);
+    if (pl->d_pre_rows) (void)hipFree(pl->d_pre_rows);
+    if (pl->d_sym_row) (void)hipFree(pl->d_sym_row);
+    if (pl->d_frame_row) (void)hipFree(pl->d_frame_row);
+    delete pl;
+    return OFDMTX_OK;
+}
+
+int ofdmtx_raw_plan_get_sizes(const ofdmtx_raw_plan *pl, ofdmtx_raw_sizes *out)
+{
+    if (!pl || !out) return OFDMTX_EINVAL;
+    *out = pl->sizes;
+    return OFDMTX_OK;
+}
+
+int ofdmtx_raw_modulate(ofdmtx_ctx *ctx, const ofdmtx_raw_plan *pl, const float *d_data, float *d_mapped,
+                        float *d_iq, void *stream)
+{
+    if (!ctx || !pl || pl->ctx != ctx || !d_iq) return OFDMTX_EINVAL;
+    if (!d_data && pl->rp.n_sym) return OFDMTX_EINVAL;
+    if (pl->rp.n_sym == 0) return OFDMTX_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    return launch_raw_n(ctx, pl->rp, reinterpret_cast<const float2 *>(d_data), reinterpret_cast<float2 *>(d_mapped),
+                        reinterpret_cast<float2 *>(d_iq), (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,157 @@
+// libofdmtx, single-message stage kernels: the bit-level functions of the reference's packet
+// utilities as separately callable operators on ONE byte string (scrambler, convolutional
+// encoder with puncturing, interleaver).  They exist so that the Python functions of the same
+// names keep their per-stage signatures; batches go through ofdmtx_encode_bits / ofdmtx_tx.
+// One thread per output byte; bytes are MSB-first bit strings.
+//
+// Citations: pu = ftw_80211_ofdm_tx/src/examples/ftw_packet_utils.py of the reference.
+
+#include "ofdm_common.h"
+
+namespace {
+
+struct StageRegime {
+    int n_cbps, n_bpsc, punct;   // punct: 0 none, 1 = 3/4, 2 = 2/3
+};
+
+// pu:39-78
+bool stage_regime(int regime, StageRegime *r)
+{
+    switch (regime) {
+    case 1: *r = {48, 1, 0}; return true;
+    case 2: *r = {48, 1, 1}; return true;
+    case 3: *r = {96, 2, 0}; return true;
+    case 4: *r = {96, 2, 1}; return true;
+    case 5: *r = {192, 4, 0}; return true;
+    case 6: *r = {192, 4, 1}; return true;
+    case 7: *r = {288, 6, 2}; return true;
+    case 8: *r = {288, 6, 1}; return true;
+    default: return false;
+    }
+}
+
+__device__ __forceinline__ uint32_t get_bit(const uint8_t *s, int64_t i)
+{
+    return i < 0 ? 0u : (uint32_t)(s[i >> 3] >> (7 - (i & 7))) & 1u;
+}
+
+// pu:344-367: bits 0..23 untouched, bit k >= 24 XOR sequence[(k - 24) % 127], then the six bits
+// from 40 + 8*Length_data on are forced to zero.  scr_word[i] holds sequence bits i .. i+31, MSB first.
+__global__ void k_stage_scramble(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, uint32_t n_bytes,
+                                 uint32_t length_data, const uint32_t *__restrict__ scr_word)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_bytes) return;
+    uint8_t v = in[b];
+    if (b >= 3u) v ^= (uint8_t)(scr_word[(8u * b - 24u) % 127u] >> 24);
+    if (b == 5u + length_data) v &= 0x03u;
+    out[b] = v;
+}
+
+// pu:280-341: rate-1/2 encoder over the whole string (register starts at zero, SIGNAL included),
+// output A (133 octal) before B (171 octal); the DATA part (coded bits from 48 on) is punctured
+// and cut to n_out_bits - 48.
+__global__ void k_stage_conv_encode(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, uint32_t out_bytes,
+                                    int punct)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= out_bytes) return;
+    uint32_t v = 0;
+    for (uint32_t i = 0; i < 8u; i++) {
+        const uint32_t j = 8u * b + i;                 // index in the output stream
+        uint32_t c = j;                                // index in the rate-1/2 stream
+        if (j >= 48u) {
+            const uint32_t q = j - 48u;
+            c = 48u + (punct == 1 ? 6u * (q / 4u) + ((q % 4u) == 3u ? 5u : q % 4u)      // keep 0,1,2,5 of 6 (pu:316-328)
+                                  : punct == 2 ? 4u * (q / 3u) + q % 3u                   // keep 0,1,2 of 4 (pu:330-341)
+                                               : q);
+        }
+        const int64_t n = c >> 1;
+        // A[n] = u[n]^u[n-2]^u[n-3]^u[n-5]^u[n-6], B[n] = u[n]^u[n-1]^u[n-2]^u[n-3]^u[n-6]  (pu:287-307)
+        uint32_t bit = get_bit(in, n) ^ get_bit(in, n - 2) ^ get_bit(in, n - 3) ^ get_bit(in, n - 6);
+        bit ^= (c & 1u) ? get_bit(in, n - 1) : get_bit(in, n - 5);
+        v |= bit << (7u - i);
+    }
+    out[b] = (uint8_t)v;
+}
+
+// pu:222-277: per OFDM symbol, bit k of the input goes to i = (N/16)(k%16) + k/16 and on to
+// j = s*(i/s) + (i + N - 16i/N) % s; the first 48 bits (SIGNAL) use N = 48 and the first step only.
+// The thread computes the inverse: which input bit lands on each of its output bits.
+__global__ void k_stage_interleave(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, uint32_t n_bytes,
+                                   int n_cbps, int n_bpsc)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_bytes) return;
+    const int R = 3 * n_bpsc, S = n_bpsc / 2 > 1 ? n_bpsc / 2 : 1;
+    uint32_t v = 0;
+    for (uint32_t i = 0; i < 8u; i++) {
+        const uint32_t o = 8u * b + i;
+        uint32_t src;
+        if (o < 48u) {
+            src = 16u * (o % 3u) + o / 3u;
+        } else {
+            const uint32_t sym = (o - 48u) / (uint32_t)n_cbps, j = (o - 48u) % (uint32_t)n_cbps;
+            const uint32_t c = j / (uint32_t)R, u = j % (uint32_t)R;
+            src = 48u + sym * (uint32_t)n_cbps + 16u * ((uint32_t)S * (u / (uint32_t)S) + ((u % (uint32_t)S) + c) % (uint32_t)S) + c;
+        }
+        v |= get_bit(in, src) << (7u - i);
+    }
+    out[b] = (uint8_t)v;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ofdmtx_scramble(ofdmtx_ctx *ctx, const uint8_t *d_in, uint32_t n_bytes, uint32_t length_data, uint8_t *d_out,
+                    void *stream)
+{
+    if (!ctx || !d_in || !d_out) return OFDMTX_EINVAL;
+    // the reference indexes the tail bits without a bound check (IndexError beyond the string)
+    if (n_bytes < 3u || 5u + (uint64_t)length_data >= n_bytes) return OFDMTX_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_stage_scramble, dim3((n_bytes + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, d_in,
+                       d_out, n_bytes, length_data, ctx->d_scr);
+    HIPCHK(hipGetLastError());
+    return OFDMTX_OK;
+}
+
+int ofdmtx_conv_encode(ofdmtx_ctx *ctx, const uint8_t *d_in, uint32_t n_bytes, int regime, uint32_t n_sym,
+                       uint8_t *d_out, void *stream)
+{
+    if (!ctx || !d_in || !d_out) return OFDMTX_EINVAL;
+    StageRegime r;
+    if (!stage_regime(regime, &r)) return OFDMTX_EREGIME;
+    const uint64_t out_bits = 48ull + (uint64_t)n_sym * (uint64_t)r.n_cbps;
+    // last rate-1/2 bit the output needs must exist in the input
+    uint64_t last = out_bits - 1;
+    if (out_bits > 48) {
+        const uint64_t q = out_bits - 49;
+        last = 48 + (r.punct == 1 ? 6 * (q / 4) + ((q % 4) == 3 ? 5 : q % 4) : r.punct == 2 ? 4 * (q / 3) + q % 3 : q);
+    }
+    if (last / 2 >= 8ull * n_bytes || out_bits / 8 > 0xFFFFFFFFull) return OFDMTX_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint32_t out_bytes = (uint32_t)(out_bits / 8);
+    hipLaunchKernelGGL(k_stage_conv_encode, dim3((out_bytes + 255u) / 256u), dim3(256), 0, (hipStream_t)stream,
+                       d_in, d_out, out_bytes, r.punct);
+    HIPCHK(hipGetLastError());
+    return OFDMTX_OK;
+}
+
+int ofdmtx_interleave(ofdmtx_ctx *ctx, const uint8_t *d_in, uint32_t n_bytes, int regime, uint8_t *d_out,
+                      void *stream)
+{
+    if (!ctx || !d_in || !d_out) return OFDMTX_EINVAL;
+    StageRegime r;
+    if (!stage_regime(regime, &r)) return OFDMTX_EREGIME;
+    // whole symbols only: the reference leaves a trailing partial symbol as zeros
+    if (n_bytes < 6u || ((uint64_t)(n_bytes - 6u) * 8u) % (uint64_t)r.n_cbps != 0) return OFDMTX_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_stage_interleave, dim3((n_bytes + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, d_in,
+                       d_out, n_bytes, r.n_cbps, r.n_bpsc);
+    HIPCHK(hipGetLastError());
+    return OFDMTX_OK;
+}
+
+}  // extern "C"
