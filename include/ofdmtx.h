@@ -93,10 +93,21 @@ int ofdmtx_destroy(ofdmtx_ctx *ctx);
 int ofdmtx_set_constellation(ofdmtx_ctx *ctx, int n_bpsc, const float *re_im, int n);
 
 /* ---- host helpers ----------------------------------------------------------------- */
+/* The static tables of examples/ftw_packet_utils.py:497-508 as the device uses them (float32,
+ * re/im interleaved): gray_const_bpsk / _qpsk / _qam16 / _qam64 and the 320-sample fft_preamble.
+ * Returns the number of floats written (4, 8, 32, 128, 640) or a negative code. */
+#define OFDMTX_TABLE_BPSK 1
+#define OFDMTX_TABLE_QPSK 2
+#define OFDMTX_TABLE_QAM16 4
+#define OFDMTX_TABLE_QAM64 6
+#define OFDMTX_TABLE_PREAMBLE 100
+int ofdmtx_get_table(int which, float *out, int n_floats);
 /* ftw.ftw_crc32 (ftw/ftw_crc32.cc:72-82): bit-reversed reflected CRC-32. */
 uint32_t ofdmtx_crc32(const uint8_t *buf, size_t len);
 /* get_info (examples/ftw_packet_utils.py:25-105) for payload_len bytes behind the 24-byte
- * MAC header.  flags as for plans (they only affect n_rows). */
+ * MAC header.  flags as for plans (they only affect n_rows).  Returns OFDMTX_ELENGTH when the
+ * MPDU exceeds what ftw_make accepts (examples/ftw_packet_utils.py:119-121); *out is filled in
+ * that case too, as get_info itself has no limit. */
 int ofdmtx_packet_info(int regime, int payload_len, double symbol_time, unsigned flags,
                        ofdmtx_pkt_info *out);
 

@@ -45,6 +45,7 @@ PROTOTYPES = {
     "ofdmtx_create": (C.c_int, [C.c_int, C.POINTER(_VP)]),
     "ofdmtx_destroy": (C.c_int, [_VP]),
     "ofdmtx_set_constellation": (C.c_int, [_VP, C.c_int, _VP, C.c_int]),
+    "ofdmtx_get_table": (C.c_int, [C.c_int, _VP, C.c_int]),
     "ofdmtx_crc32": (C.c_uint32, [C.c_char_p, C.c_size_t]),
     "ofdmtx_packet_info": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_uint, C.POINTER(PktInfo)]),
     "ofdmtx_plan_uniform": (C.c_int, [_VP, C.c_uint64, C.c_int, C.c_uint32, C.c_uint64, C.c_double,
@@ -113,3 +114,16 @@ def packet_info(regime, payload_len, symbol_time=4.0, flags=F_PREAMBLE | F_ZEROG
 def crc32(data):
     data = bytes(data)
     return load().ofdmtx_crc32(data, len(data))
+
+
+def get_table(which):
+    """Static table `which` (TABLE_*) as a complex64 numpy array."""
+    import numpy as np
+    buf = np.zeros(640, dtype=np.float32)
+    n = load().ofdmtx_get_table(int(which), buf.ctypes.data, len(buf))
+    if n < 0:
+        check(n)
+    return buf[:n].copy().view(np.complex64)
+
+
+TABLE_BPSK, TABLE_QPSK, TABLE_QAM16, TABLE_QAM64, TABLE_PREAMBLE = 1, 2, 4, 6, 100

@@ -1224,7 +1224,6 @@ int ofdmtx_packet_info(int regime, int payload_len, double symbol_time, unsigned
     if (regime < 1 || regime > 8) return OFDMTX_EREGIME;
     const RegimeInfo ri = regime_info(regime);
     const int mpdu = 24 + payload_len;
-    if (mpdu + 4 > MAXLEN) return OFDMTX_ELENGTH;                       // pu:119-121
     const int nbits = 16 + 32 + 6 + 8 * mpdu;
     out->n_cbps = ri.n_cbps;
     out->n_bpsc = ri.n_bpsc;
@@ -1238,7 +1237,8 @@ int ofdmtx_packet_info(int regime, int payload_len, double symbol_time, unsigned
     out->msg_len = 6 + out->n_sym * ri.n_cbps / 8;
     out->n_rows = ((flags & OFDMTX_F_PREAMBLE) ? PRE_ROWS : 0) + 1 + out->n_sym +
                   ((flags & OFDMTX_F_ZEROGAP) ? GAP_ROWS : 0);
-    return OFDMTX_OK;
+    // the length limit is ftw_make's (pu:119-121), get_info itself has none: *out is complete either way
+    return mpdu + 4 > MAXLEN ? OFDMTX_ELENGTH : OFDMTX_OK;
 }
 
 int ofdmtx_create(int device, ofdmtx_ctx **out)
@@ -1321,6 +1321,23 @@ int ofdmtx_set_constellation(ofdmtx_ctx *c, int n_bpsc, const float *re_im, int 
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpy(c->d_lut + off, re_im, (size_t)n * sizeof(float2), hipMemcpyHostToDevice));
     return OFDMTX_OK;
+}
+
+int ofdmtx_get_table(int which, float *out, int n_floats)
+{
+    const float *src;
+    int n;
+    switch (which) {
+    case OFDMTX_TABLE_BPSK: src = OFDMTX_CONST_DEFAULT; n = 4; break;
+    case OFDMTX_TABLE_QPSK: src = OFDMTX_CONST_DEFAULT + 4; n = 8; break;
+    case OFDMTX_TABLE_QAM16: src = OFDMTX_CONST_DEFAULT + 12; n = 32; break;
+    case OFDMTX_TABLE_QAM64: src = OFDMTX_CONST_DEFAULT + 44; n = 128; break;
+    case OFDMTX_TABLE_PREAMBLE: src = OFDMTX_PREAMBLE; n = 640; break;
+    default: return OFDMTX_EINVAL;
+    }
+    if (!out || n_floats < n) return OFDMTX_EINVAL;
+    memcpy(out, src, (size_t)n * sizeof(float));
+    return n;
 }
 
 static inline uint32_t align16(uint32_t v) { return (v + 15u) & ~15u; }

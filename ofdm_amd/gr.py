@@ -1,0 +1,207 @@
+"""The few GNU Radio runtime objects the reference's transmit scripts touch (messages, the
+bounded message queue, sinks, multiply_const, top_block), reduced to what a batch modulator
+needs.  There is no scheduler: a top_block records how the transmit path is wired to its sink
+and the path pushes finished IQ batches downstream.
+
+Only the call surface used by the reference's ftw_ofdm.py / ftw_ofdm_tx_uhd.py is provided.
+"""
+import collections
+import threading
+
+import numpy as np
+
+sizeof_gr_complex = 8
+sizeof_char = 1
+sizeof_float = 4
+RT_OK = 0
+
+
+def enable_realtime_scheduling():
+    """Nothing to schedule: kernels run on a HIP stream."""
+    return RT_OK
+
+
+class message(object):
+    """gr.message: type 1 marks end of stream (examples/ftw_ofdm.py:199)."""
+
+    def __init__(self, type=0, arg1=0.0, arg2=0.0, data=b""):
+        self._type, self._arg1, self._arg2, self._data = type, arg1, arg2, bytes(data)
+
+    def type(self):
+        return self._type
+
+    def to_string(self):
+        return self._data
+
+    def length(self):
+        return len(self._data)
+
+
+def message_from_string(s, type=0, arg1=0.0, arg2=0.0):
+    return message(type, arg1, arg2, s if isinstance(s, (bytes, bytearray)) else s.encode("latin-1"))
+
+
+class msg_queue(object):
+    """gr.msg_queue(limit): insert_tail blocks while `limit` messages wait (0 = unbounded)."""
+
+    def __init__(self, limit=0):
+        self._limit = limit
+        self._q = collections.deque()
+        self._cv = threading.Condition()
+
+    def limit(self):
+        return self._limit
+
+    def count(self):
+        with self._cv:
+            return len(self._q)
+
+    def empty_p(self):
+        return self.count() == 0
+
+    def full_p(self):
+        return self._limit != 0 and self.count() >= self._limit
+
+    def insert_tail(self, msg):
+        with self._cv:
+            while self._limit and len(self._q) >= self._limit:
+                self._cv.wait()
+            self._q.append(msg)
+            self._cv.notify_all()
+
+    def delete_head(self):
+        with self._cv:
+            while not self._q:
+                self._cv.wait()
+            m = self._q.popleft()
+            self._cv.notify_all()
+            return m
+
+    def delete_head_nowait(self):
+        with self._cv:
+            if not self._q:
+                return None
+            m = self._q.popleft()
+            self._cv.notify_all()
+            return m
+
+    def flush(self):
+        with self._cv:
+            self._q.clear()
+            self._cv.notify_all()
+
+
+def _to_numpy(x):
+    if hasattr(x, "detach"):
+        x = x.detach().cpu().numpy()
+    return np.ascontiguousarray(x)
+
+
+class file_sink(object):
+    """gr.file_sink(itemsize, filename): raw little-endian items appended to a file
+    (examples/ftw_ofdm_tx_uhd.py:66-67: complex64 = float32 I,Q pairs)."""
+
+    def __init__(self, itemsize, filename):
+        self.itemsize = itemsize
+        self.filename = filename
+        self._f = open(filename, "wb")
+
+    def write(self, items):
+        _to_numpy(items).tofile(self._f)
+
+    def close(self):
+        if self._f:
+            self._f.close()
+            self._f = None
+
+
+class null_sink(object):
+    def __init__(self, itemsize):
+        self.itemsize = itemsize
+        self.items_seen = 0
+
+    def write(self, items):
+        self.items_seen += int(items.numel() if hasattr(items, "numel") else np.size(items))
+
+    def close(self):
+        pass
+
+
+class vector_sink_c(object):
+    """Keeps everything it receives (host memory)."""
+
+    def __init__(self, vlen=1):
+        self._chunks = []
+
+    def write(self, items):
+        self._chunks.append(_to_numpy(items).reshape(-1))
+
+    def data(self):
+        return np.concatenate(self._chunks) if self._chunks else np.zeros(0, np.complex64)
+
+    def close(self):
+        pass
+
+
+class multiply_const_cc(object):
+    def __init__(self, k):
+        self._k = k
+
+    def k(self):
+        return self._k
+
+    def set_k(self, k):
+        self._k = k
+
+
+class hier_block2(object):
+    def __init__(self, name="", input_signature=None, output_signature=None):
+        self._name = name
+
+    def name(self):
+        return self._name
+
+
+class top_block(hier_block2):
+    """connect(source, [multiply_const_cc], sink...) wires a transmit path; start()/wait()/run()
+    keep the reference's control flow (examples/ftw_ofdm_tx_uhd.py:155-175)."""
+
+    def __init__(self, name="top_block"):
+        hier_block2.__init__(self, name)
+        self._sources = []
+        self._sinks = []
+
+    def connect(self, *blocks):
+        src = blocks[0]
+        if not hasattr(src, "_attach"):
+            raise TypeError("the first block of a connection must be a transmit path")
+        gain = None
+        sinks = []
+        for b in blocks[1:]:
+            if isinstance(b, multiply_const_cc):
+                gain = b
+            elif hasattr(b, "write"):
+                sinks.append(b)
+            else:
+                raise TypeError("cannot connect %r" % (b,))
+        src._attach(gain, sinks)
+        if src not in self._sources:
+            self._sources.append(src)
+        self._sinks.extend(sinks)
+
+    def start(self):
+        for s in self._sources:
+            s._start()
+
+    def wait(self):
+        for s in self._sources:
+            s._finish()
+        for k in self._sinks:
+            k.close()
+
+    def stop(self):
+        pass
+
+    def run(self):
+        self.start()
+        self.wait()
