@@ -1,0 +1,113 @@
+"""The headline configuration at full size (54 Mbit/s, 10^6 packets of 1500 bytes on one GPU:
+48 GB of IQ) through properties that need no full-size oracle run:
+  * the fused kernel and the two-kernel path agree bit for bit over the whole batch;
+  * randomly chosen packets match the oracle (bytes bit-exact, IQ <= 1e-5 relative L2 per row);
+  * structure: every packet starts with the same four preamble rows and ends with 13 zero rows;
+  * determinism under the pilot schedule: packets 127 apart with equal payloads give equal IQ
+    (the polarity index advances by 58 symbols per packet, modulo 127).
+Mixed-rate ragged batch (all eight rates, payload lengths 1..2304): same checks at 2*10^5 packets.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+REL_L2_TOL = 1e-5
+
+
+def rel_l2_rows(got, ref):
+    got = got.reshape(-1, 80).astype(np.complex128)
+    ref = ref.reshape(-1, 80)
+    num = np.sqrt((np.abs(got - ref) ** 2).sum(axis=1))
+    den = np.sqrt((np.abs(ref) ** 2).sum(axis=1))
+    assert np.all(num[den == 0] == 0)
+    return np.where(den == 0, 0.0, num / np.where(den == 0, 1.0, den))
+
+
+def equal_chunked(a, b, chunk=1 << 28):
+    a, b = a.view(torch.int32).reshape(-1), b.view(torch.int32).reshape(-1)
+    for i in range(0, a.numel(), chunk):
+        if not torch.equal(a[i:i + chunk], b[i:i + chunk]):
+            return False
+    return True
+
+
+def test_config2_one_million_packets(txctx, c_oracle):
+    n, ln, regime = 1_000_000, 1500, 8
+    free, _ = torch.cuda.mem_get_info()
+    if free < 110e9:
+        pytest.skip("needs ~100 GB of free HBM")
+    dev = txctx.device
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(2)
+    payloads = torch.randint(0, 256, (n * ln,), dtype=torch.uint8, device=dev, generator=gen)
+    # equal payloads 127 packets apart, for the determinism property
+    pv = payloads.view(n, ln)
+    pv[127 * 5 + 3] = pv[3]
+    pv[999_000] = pv[999_000 - 127 * 40]
+    plan = txctx.plan_uniform(n, regime, ln)
+    assert plan.n_samples == 6_000_000_000
+    iq = plan.tx(payloads)
+    msg = plan.encode_bits(payloads)
+    iq2 = plan.modulate(msg)
+    torch.cuda.synchronize()
+    assert equal_chunked(iq, iq2), "fused kernel differs from encode_bits + modulate"
+    del iq2
+    rows = iq.view(n, 75, 80)
+    # structure
+    pre = rows[:, :4]
+    assert bool((pre.view(torch.int64) == pre[:1].view(torch.int64)).all())
+    assert bool((rows[:, 62:].view(torch.int64) == 0).all())
+    # determinism under the pilot schedule
+    assert torch.equal(rows[127 * 5 + 3].view(torch.int64), rows[3].view(torch.int64))
+    assert torch.equal(rows[999_000].view(torch.int64), rows[999_000 - 127 * 40].view(torch.int64))
+    assert not torch.equal(rows[4].view(torch.int64), rows[3].view(torch.int64))
+    # random packets against the oracle
+    lay_msg = 2064
+    rng = np.random.default_rng(7)
+    for i in [0, 1, n - 1] + list(rng.integers(0, n, 29)):
+        i = int(i)
+        pl = pv[i].cpu().numpy().tobytes()
+        ref = c_oracle.encode_bits(pl, regime)
+        got_msg = msg[i * lay_msg:i * lay_msg + 2058].cpu().numpy().tobytes()
+        assert got_msg == ref["interleaved"], "packet %d" % i
+        want = c_oracle.modulate(ref["interleaved"], regime, (i * 58) % 127, 0.3, 3)["iq64"]
+        err = rel_l2_rows(rows[i].cpu().numpy(), want)
+        assert err.max() <= REL_L2_TOL, (i, err.max())
+
+
+def test_config3_mixed_rate_ragged(txctx, c_oracle):
+    n = 200_000
+    rng = np.random.default_rng(3)
+    regimes = rng.integers(1, 9, n).astype(np.uint8)
+    lens = rng.integers(1, 2305, n).astype(np.uint32)
+    dev = txctx.device
+    total = int(lens.sum())
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(3)
+    payloads = torch.randint(0, 256, (total,), dtype=torch.uint8, device=dev, generator=gen)
+    plan = txctx.plan_ragged(regimes, lens)
+    free, _ = torch.cuda.mem_get_info()
+    if free < 2.2 * plan.n_samples * 8:
+        pytest.skip("not enough free HBM")
+    iq = plan.tx(payloads)
+    taps = plan.encode_bits(payloads, taps=True)
+    iq2 = plan.modulate(taps["interleaved"])
+    torch.cuda.synchronize()
+    assert equal_chunked(iq, iq2)
+    lay = plan.layout()
+    pay_off = np.concatenate([[0], np.cumsum(lens.astype(np.int64))])
+    for i in [0, n - 1] + list(rng.integers(0, n, 40)):
+        i = int(i)
+        pl = payloads[pay_off[i]:pay_off[i + 1]].cpu().numpy().tobytes()
+        ref = c_oracle.encode_bits(pl, int(regimes[i]))
+        mo, ml = int(lay["msg_off"][i]), int(lay["msg_len"][i])
+        po, pn = int(lay["plcp_off"][i]), int(lay["plcp_len"][i])
+        assert taps["interleaved"][mo:mo + ml].cpu().numpy().tobytes() == ref["interleaved"]
+        assert taps["coded"][mo:mo + ml].cpu().numpy().tobytes() == ref["coded"]
+        assert taps["scrambled"][po:po + pn].cpu().numpy().tobytes() == ref["scrambled"]
+        want = c_oracle.modulate(ref["interleaved"], int(regimes[i]), int(lay["pilot_base"][i]), 0.3, 3)["iq64"]
+        a = int(lay["sample_off"][i])
+        err = rel_l2_rows(iq[a:a + len(want)].cpu().numpy(), want)
+        assert err.max() <= REL_L2_TOL, (i, err.max())
