@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Secondary measurements (not the headline bench line): the mixed-rate ragged batch and the
+variable-size modulator, each as one JSON line with the kernel time from events on the launch
+stream and the algorithmic HBM bytes per launch.
+
+    python tools/bench_extra.py [--steps K]
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from ofdm_amd import raw  # noqa: E402
+from ofdm_amd.batch import TxContext  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0
+
+
+def timed(fn, steps, warmup=2):
+    for _ in range(warmup):
+        fn()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    torch.cuda.synchronize()
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    return float(np.median([a.elapsed_time(b) for a, b in ev]))
+
+
+def line(name, ms, alg_bytes, samples, extra):
+    gbs = alg_bytes / (ms * 1e-3) / 1e9
+    out = {"workload": name, "kernel_ms": ms, "Msamples_per_s": samples / (ms * 1e-3) / 1e6,
+           "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg_bytes}}
+    out.update(extra)
+    print(json.dumps(out), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--ragged-packets", type=int, default=400_000)
+    ap.add_argument("--raw-symbols", type=int, default=1 << 20)
+    a = ap.parse_args()
+    ctx = TxContext(0)
+    dev = ctx.device
+
+    # mixed-rate ragged batch: all eight rates, payload lengths 1..2304 bytes
+    rng = np.random.default_rng(3)
+    n = a.ragged_packets
+    regimes = rng.integers(1, 9, n).astype(np.uint8)
+    lens = rng.integers(1, 2305, n).astype(np.uint32)
+    payloads = torch.randint(0, 256, (int(lens.sum()),), dtype=torch.uint8, device=dev)
+    plan = ctx.plan_ragged(regimes, lens)
+    iq = plan.alloc_iq()
+    ms = timed(lambda: plan.tx(payloads, out=iq), a.steps)
+    line("mixed-rate ragged batch, payload -> IQ (fused kernel)", ms, int(lens.sum()) + plan.n_samples * 8,
+         plan.n_samples, {"packets": n})
+    msg = plan.alloc_msg()
+    ms_e = timed(lambda: plan.encode_bits(payloads, out=msg), a.steps)
+    ms_m = timed(lambda: plan.modulate(msg, out=iq), a.steps)
+    line("mixed-rate ragged batch, mapper messages -> IQ (k_modulate)", ms_m, plan.msg_bytes + plan.n_samples * 8,
+         plan.n_samples, {"packets": n, "k_encode_bits_ms": ms_e})
+    del iq, msg, payloads, plan
+
+    # uniform batches of the other rates, fused kernel
+    for regime in (1, 3, 5, 7):
+        npk = 200_000 if regime == 1 else 500_000
+        plan = ctx.plan_uniform(npk, regime, 1500)
+        payloads = torch.randint(0, 256, (npk * 1500,), dtype=torch.uint8, device=dev)
+        iq = plan.alloc_iq()
+        ms = timed(lambda: plan.tx(payloads, out=iq), a.steps)
+        line("regime %d, %d x 1500-byte packets, payload -> IQ (fused kernel)" % (regime, npk), ms,
+             npk * 1500 + plan.n_samples * 8, plan.n_samples, {"packets": npk})
+        del iq, payloads, plan
+
+    # variable-size modulator: frames of 16 data symbols + 3 preamble symbols, unit QPSK
+    class O(object):
+        num_preambles, half_sync, verbose, log = 2, True, False, False
+    for nfft, cp in ((256, 64), (256, 32), (1024, 256), (1024, 128), (64, 16)):
+        o = O()
+        o.fft_length, o.occupied_tones, o.cp_length = nfft, int(0.8125 * nfft), cp
+        p = raw.ofdm_params(o)
+        n_sym = a.raw_symbols if nfft <= 256 else a.raw_symbols // 4
+        n_frames = n_sym // 16
+        plan = raw.plan_frames(ctx, p.fft_length, p.cp_length, p.padded_carriers, p.padded_preambles, n_frames, 16)
+        ph = torch.randint(0, 4, (n_frames * 16 * p.data_tones,), device=dev)
+        data = torch.polar(torch.ones_like(ph, dtype=torch.float32), (2 * ph + 1) * (np.pi / 4)).contiguous()
+        iq = torch.empty(plan.n_samples, dtype=torch.complex64, device=dev)
+        ms = timed(lambda: plan.modulate(data, out=iq), a.steps)
+        line("variable-size modulator N=%d cp=%d, %d data symbols in frames of 16 (+3 preamble rows)"
+             % (nfft, cp, n_frames * 16), ms, data.numel() * 8 + plan.n_samples * 8, plan.n_samples,
+             {"data_symbols": n_frames * 16})
+        del iq, data, plan
+
+
+if __name__ == "__main__":
+    main()
