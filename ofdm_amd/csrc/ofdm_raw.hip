@@ -163,15 +163,26 @@ k_raw_modulate(RawParams R, const float2 *__restrict__ data, float2 *__restrict_
         if (active && t < L) {
             v2f x[M];
             const float2 *dsym = data + (size_t)sym * R.data_tones;
+            // all loads first, nothing between them that could make the compiler wait for one
+            // load before it issues the next (a tap store in this loop did exactly that)
+            int code[M];
+            float2 d[M];
+#pragma unroll
+            for (int m = 0; m < M; m++) code[m] = s_src[t + L * m];
+#pragma unroll
+            for (int m = 0; m < M; m++) d[m] = dsym[code[m] >= 0 ? code[m] : 0];
 #pragma unroll
             for (int m = 0; m < M; m++) {
-                const int k = t + L * m;
-                const int code = s_src[k];
-                const float2 d = dsym[code >= 0 ? code : 0];
-                v2f v = {d.x, d.y};
-                if (code < 0) v = (v2f){code == -2 ? 1.f : (code == -3 ? -1.f : 0.f), 0.f};
-                if (mapped) mapped[(size_t)sym * N + ((k + N / 2) & (N - 1))] = make_float2(v.x, v.y);
+                v2f v = {d[m].x, d[m].y};
+                if (code[m] < 0) v = (v2f){code[m] == -2 ? 1.f : (code[m] == -3 ? -1.f : 0.f), 0.f};
                 x[bit_reverse(m, M)] = v;
+            }
+            if (mapped) {
+#pragma unroll
+                for (int m = 0; m < M; m++) {
+                    const v2f v = x[bit_reverse(m, M)];
+                    mapped[(size_t)sym * N + ((t + L * m + N / 2) & (N - 1))] = make_float2(v.x, v.y);
+                }
             }
             idft_reg<M>(x);
 #pragma unroll
