@@ -579,11 +579,13 @@ __device__ __forceinline__ uint32_t slot_word(const uint32_t (&Aw)[NA], const ui
     return v;
 }
 
+// Every word goes to LDS as soon as it is complete (dst[WORD]): holding the 13 words back
+// for one burst of stores costs a dozen registers the encoder does not have.
 template <int NBPSC, int PUNCT, int NA, int... WORD>
 __device__ __forceinline__ void slot_words(const uint32_t (&Aw)[NA], const uint32_t (&Bw)[NA], uint32_t neg,
-                                           uint32_t (&out)[SLOT_ROW_WORDS], std::integer_sequence<int, WORD...>)
+                                           uint32_t *dst, std::integer_sequence<int, WORD...>)
 {
-    ((out[WORD] = slot_word<NBPSC, PUNCT, WORD>(Aw, Bw, neg, std::make_integer_sequence<int, 4 * NBPSC>{}),
+    ((dst[WORD] = slot_word<NBPSC, PUNCT, WORD>(Aw, Bw, neg, std::make_integer_sequence<int, 4 * NBPSC>{}),
       __builtin_amdgcn_sched_barrier(0)), ...);
 }
 
@@ -620,10 +622,7 @@ __device__ __forceinline__ void symbol_slots(const uint32_t *U, uint32_t *SI, ui
             Bw[i] = common ^ y5 ^ y4;
         }
         const uint32_t neg = pilot_negative((pilot_base + sidx) % 127u, pneg_lo, pneg_hi);
-        uint32_t out[SLOT_ROW_WORDS];
-        slot_words<NBPSC, PUNCT>(Aw, Bw, neg, out, std::make_integer_sequence<int, SLOT_ROW_WORDS>{});
-#pragma unroll
-        for (int i = 0; i < SLOT_ROW_WORDS; i++) SI[SLOT_ROW_WORDS * lane + i] = out[i];
+        slot_words<NBPSC, PUNCT>(Aw, Bw, neg, SI + SLOT_ROW_WORDS * lane, std::make_integer_sequence<int, SLOT_ROW_WORDS>{});
     }
 }
 

@@ -1,0 +1,26 @@
+"""End-to-end rate of the drop-in path: host payload bytes in (send_pkt), IQ to a host sink."""
+import os, sys, time
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+from ofdm_amd import ftw_ofdm_tx, gr
+
+class O: pass
+o = O(); o.regime="8"; o.bandwidth=20e6; o.swapIQ=False; o.log=False; o.role=None; o.tx_amplitude=0.3
+o.to_file=None; o.from_file=None; o.tx_freq=None
+rng = np.random.default_rng(0)
+n = 100000
+pay = [rng.integers(0,256,1500,dtype=np.uint8).tobytes() for _ in range(64)]
+for sink_kind in ("null", "host"):
+    tb = ftw_ofdm_tx.my_top_block(o, pay[0])
+    if sink_kind == "host":
+        class HostSink:
+            def __init__(s): s.n = 0
+            def write(s, t): s.n += t.cpu().numel()
+            def close(s): pass
+        tb.connect(tb.txpath, tb.amp, HostSink())
+    tb.start()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for i in range(n): tb.txpath.send_pkt(pay[i & 63])
+    tb.txpath.send_pkt(eof=True); tb.wait()
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print("%s sink: %d packets in %.3f s = %.1f Msamples/s (%.2f GB/s of IQ)" % (sink_kind, n, dt, n*6000/dt/1e6, n*48000/dt/1e9))
