@@ -589,11 +589,11 @@ __device__ __forceinline__ void slot_words(const uint32_t (&Aw)[NA], const uint3
       __builtin_amdgcn_sched_barrier(0)), ...);
 }
 
-// Slot rows of the DATA symbols c0 + lane (symbol 0 is SIGNAL and is not handled here), one
-// lane per symbol, into SI row `lane`.  Encoder, puncturing and interleaver as in
-// encode_data_symbols; pilot polarity of symbol index sidx is entry (pilot_base + sidx) % 127.
+// Slot rows of the DATA symbols with 0-based index d0 + lane (the SIGNAL symbol is not handled here), one
+// lane per symbol, into the row SI points at + lane.  Encoder, puncturing and interleaver as in
+// encode_data_symbols; the pilot polarity of DATA symbol d is entry (pilot_base + 1 + d) % 127.
 template <int NBPSC, int PUNCT>
-__device__ __forceinline__ void symbol_slots(const uint32_t *U, uint32_t *SI, uint32_t c0, uint32_t n_sym,
+__device__ __forceinline__ void symbol_slots(const uint32_t *U, uint32_t *SI, uint32_t d0, uint32_t n_sym,
                                              uint32_t pilot_base, uint64_t pneg_lo, uint64_t pneg_hi, int lane)
 {
     constexpr int N = 48 * NBPSC;
@@ -601,9 +601,9 @@ __device__ __forceinline__ void symbol_slots(const uint32_t *U, uint32_t *SI, ui
     constexpr int NA = (NDBPS + 31) / 32;
     constexpr int NX = NA + 1;
 
-    const uint32_t sidx = c0 + (uint32_t)lane;
-    if (sidx >= 1u && sidx <= n_sym) {
-        const uint32_t b0 = 18u + (sidx - 1u) * NDBPS;
+    const uint32_t d = d0 + (uint32_t)lane;
+    if (d < n_sym) {
+        const uint32_t b0 = 18u + d * NDBPS;
         const uint32_t w0 = b0 >> 5, o = b0 & 31u;
         uint32_t X[NX];
 #pragma unroll
@@ -621,7 +621,7 @@ __device__ __forceinline__ void symbol_slots(const uint32_t *U, uint32_t *SI, ui
             Aw[i] = common ^ y4 ^ y1;
             Bw[i] = common ^ y5 ^ y4;
         }
-        const uint32_t neg = pilot_negative((pilot_base + sidx) % 127u, pneg_lo, pneg_hi);
+        const uint32_t neg = pilot_negative((pilot_base + 1u + d) % 127u, pneg_lo, pneg_hi);
         slot_words<NBPSC, PUNCT>(Aw, Bw, neg, SI + SLOT_ROW_WORDS * lane, std::make_integer_sequence<int, SLOT_ROW_WORDS>{});
     }
 }
@@ -979,13 +979,13 @@ k_modulate(PlanParams P, DevTables T, const uint8_t *__restrict__ msg, float2 *_
 //   1. scrambles its packet into LDS (scramble_packet),
 //   2. copies the preamble rows and zeroes the gap rows (coalesced stores that drain while the
 //      wave goes on computing),
-//   3. per chunk of up to 64 symbols: builds the symbols' slot rows, one lane per symbol
+//   3. per chunk of up to 64 DATA symbols: builds the symbols' slot rows, one lane per symbol
 //      (SIGNAL: one lane per carrier), then
 //   4. emits the chunk's rows 8 at a time, 8 lanes per symbol: the lane fetches its 8 decimated
 //      carriers straight from the LUT by slot byte and runs ifft64_emit.
 // Dynamic LDS per wave: [0, a_words) natural MPDU, later the slot rows; then 8*RS float2 of FFT
 // transposition / row staging; the scrambled words U live in the staging area when the plan's
-// packets have at most 64 symbols (one chunk: U is dead before the first group), otherwise
+// packets have at most 64 DATA symbols (one chunk: U is dead before the first group), otherwise
 // behind it (u_off).
 
 constexpr int TX_WAVES = 8;
@@ -1079,10 +1079,13 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads, float2 *__
         }
         out += (size_t)pre_rows * (SYM_LEN / 2);
 
-        for (uint32_t c0 = 0; c0 < sym_rows; c0 += 64u) {
+        // chunks of up to 64 DATA symbols (one per lane); the first chunk also carries the SIGNAL
+        // symbol, in slot row 0, so its DATA rows sit one row further down
+        for (uint32_t d0 = 0; d0 == 0 || d0 < k.n_sym; d0 += 64u) {
+            const uint32_t shift = d0 == 0 ? 1u : 0u;
             SEC("e4_signal");
             // ---- SIGNAL row: 48 coded bits (N = 48: first permutation only, pu:245-249), BPSK
-            if (c0 == 0) {
+            if (d0 == 0) {
                 const uint32_t t = 63u - lane;            // ballot bit `lane` = carrier 63 - lane
                 uint32_t bi = 0;
                 if (t < 48u) bi = coded_bit(U, 16u * (t % 3u) + t / 3u);
@@ -1099,14 +1102,14 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads, float2 *__
             // ---- DATA rows.  REGIME != 0: the batch has one regime, known when the kernel was
             // chosen, and only that instantiation is compiled in; 0 dispatches per packet.
             switch (REGIME ? (uint32_t)REGIME : k.regime) {
-            case 1: symbol_slots<1, 0>(U, SI, c0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
-            case 2: symbol_slots<1, 1>(U, SI, c0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
-            case 3: symbol_slots<2, 0>(U, SI, c0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
-            case 4: symbol_slots<2, 1>(U, SI, c0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
-            case 5: symbol_slots<4, 0>(U, SI, c0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
-            case 6: symbol_slots<4, 1>(U, SI, c0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
-            case 7: symbol_slots<6, 2>(U, SI, c0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
-            default: symbol_slots<6, 1>(U, SI, c0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
+            case 1: symbol_slots<1, 0>(U, SI + SLOT_ROW_WORDS * shift, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
+            case 2: symbol_slots<1, 1>(U, SI + SLOT_ROW_WORDS * shift, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
+            case 3: symbol_slots<2, 0>(U, SI + SLOT_ROW_WORDS * shift, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
+            case 4: symbol_slots<2, 1>(U, SI + SLOT_ROW_WORDS * shift, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
+            case 5: symbol_slots<4, 0>(U, SI + SLOT_ROW_WORDS * shift, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
+            case 6: symbol_slots<4, 1>(U, SI + SLOT_ROW_WORDS * shift, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
+            case 7: symbol_slots<6, 2>(U, SI + SLOT_ROW_WORDS * shift, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
+            default: symbol_slots<6, 1>(U, SI + SLOT_ROW_WORDS * shift, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
             }
             wave_sync();
 
@@ -1118,7 +1121,8 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads, float2 *__
             const int l = lane_r & 7, g = lane_r >> 3;
             const uint32_t sel_lo = s_win[l][0], sel_hi = s_win[l][1], slot_sh = s_win[l][3];
             const uint32_t slot_word0 = SLOT_ROW_WORDS * (uint32_t)g + s_win[l][2];
-            const uint32_t rows_chunk = sym_rows - c0 < 64u ? sym_rows - c0 : 64u;
+            const uint32_t rows_chunk = (k.n_sym - d0 < 64u ? k.n_sym - d0 : 64u) + shift;
+            const uint32_t row_base = d0 == 0 ? 0u : d0 + 1u;           // first output row of the chunk
             for (uint32_t r0 = 0; r0 < rows_chunk; r0 += 8u) {
                 SEC("map");
                 const int type = r0 + (uint32_t)g < rows_chunk ? 1 : 3;
@@ -1137,7 +1141,7 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads, float2 *__
                     }
                 }
                 ifft64_emit<true>(type, 0u, x, true, l, g, lane_r, buf, nullptr, reinterpret_cast<const v2f *>(s_tw),
-                                  swap_iq, out + (size_t)(c0 + r0) * (SYM_LEN / 2),
+                                  swap_iq, out + (size_t)(row_base + r0) * (SYM_LEN / 2),
                                   rows_chunk - r0 < 8u ? rows_chunk - r0 : 8u);
                 SEC("end");
                 wave_sync();
@@ -1347,7 +1351,7 @@ static inline uint32_t align16(uint32_t v) { return (v + 15u) & ~15u; }
 static inline uint32_t tx_words_for(const ofdmtx_pkt_info &pi)
 {
     const uint32_t d = (uint32_t)(pi.plcp_len + 3) / 4 + 4;
-    const uint32_t rows = (uint32_t)pi.n_sym + 1 < 64u ? (uint32_t)pi.n_sym + 1 : 64u;
+    const uint32_t rows = (uint32_t)pi.n_sym + 1 < 65u ? (uint32_t)pi.n_sym + 1 : 65u;
     const uint32_t m = rows * SLOT_ROW_WORDS + 3;
     const uint32_t w = d > m ? d : m;
     return (w + 3u) & ~3u;
@@ -1648,7 +1652,7 @@ int ofdmtx_tx(ofdmtx_ctx *ctx, const ofdmtx_plan *pl, const uint8_t *d_payloads,
     if (pl->pp.n_pkts == 0) return OFDMTX_OK;
     HIPCHK(hipSetDevice(ctx->device));
     // one chunk: U shares the staging area; several chunks: U needs a region of its own
-    const bool one_chunk = pl->max_sym_rows <= 64u;
+    const bool one_chunk = pl->max_sym_rows <= 65u;
     const uint32_t a_words = pl->tx_a_words;
     const uint32_t u_off = one_chunk ? a_words : a_words + (uint32_t)TX_B_WORDS;
     const uint32_t wave_words = a_words + (uint32_t)TX_B_WORDS + (one_chunk ? 0u : pl->tx_u_words);

@@ -120,3 +120,23 @@ def test_stream_pilot_counter_matches_flowgraph_order(txctx):
     plan = txctx.plan_uniform(300, 8, 1500)
     pb = plan.layout()["pilot_base"]
     assert np.array_equal(pb, (np.arange(300) * 58) % 127)
+
+
+@pytest.mark.parametrize("regime,n_sym", [(8, 63), (8, 64), (8, 65), (8, 117), (7, 64), (1, 64), (1, 65), (3, 128), (3, 129), (3, 130)])
+def test_symbol_chunk_boundaries(txctx, c_oracle, regime, n_sym):
+    """The fused kernel builds slot rows for 64 DATA symbols at a time: packets whose symbol
+    count sits on either side of that boundary, uniform and inside a ragged batch."""
+    n_dbps = {1: 24, 3: 48, 7: 192, 8: 216}[regime]
+    payload_len = (n_sym * n_dbps - 54) // 8 - 24            # the longest payload with exactly n_sym symbols
+    assert _lib.packet_info(regime, payload_len).n_sym == n_sym
+    rng = np.random.default_rng(100 * regime + n_sym)
+    n = 3
+    payloads = rng.integers(0, 256, n * payload_len, dtype=np.uint8)
+    flags = _lib.F_PREAMBLE | _lib.F_ZEROGAP
+    plan = txctx.plan_uniform(n, regime, payload_len, pilot_start=100, flags=flags, amp=0.3)
+    check_plan(plan, payloads, [payload_len] * n, [regime] * n, c_oracle, flags, 0.3)
+    lens = [payload_len, 10, payload_len]
+    regs = [regime, 5, regime]
+    pay = rng.integers(0, 256, sum(lens), dtype=np.uint8)
+    plan = txctx.plan_ragged(regs, lens, pilot_start=100, flags=flags, amp=0.3)
+    check_plan(plan, pay, lens, regs, c_oracle, flags, 0.3)
