@@ -1,11 +1,13 @@
 // libofdmtx: batched 802.11a OFDM transmit chain for gfx950 (MI355X).
 //
-// Two kernels cover the path:
-//   k_encode_bits : payload -> PLCP bytes -> scrambler -> K=7 conv. encoder + puncture ->
-//                   interleaver (one wavefront per packet, bits staged in LDS)
-//   k_modulate    : mapper message -> constellation + pilots + carrier map -> 64-point
-//                   inverse FFT (radix 8x8, eight lanes per OFDM symbol) -> cyclic prefix,
-//                   scale, preamble / zero-gap rows -> fully coalesced 16-byte stores
+// Kernels (one wavefront per packet):
+//   k_tx          : payload -> PLCP bits -> scrambler -> K=7 conv. encoder + puncture ->
+//                   interleaver -> constellation + pilots + carrier map -> 64-point inverse FFT
+//                   (radix 8x8, eight lanes per OFDM symbol) -> cyclic prefix, scale, preamble /
+//                   zero-gap rows -> fully coalesced 16-byte stores; with FROM_MSG the same
+//                   symbol-level part fed from mapper messages (ofdmtx_modulate)
+//   k_encode_bits : the bit-level part alone, writing the mapper messages and the optional
+//                   PLCP / scrambled / coded taps
 // The output of a batch is one dense stream of 80-sample rows (640 B each); a wavefront
 // produces eight consecutive rows = 5 KiB of contiguous IQ per iteration.
 //
@@ -536,6 +538,10 @@ __device__ __forceinline__ uint32_t pilot_negative(uint32_t pidx, uint64_t pneg_
     return (uint32_t)((pidx < 64u ? pneg_lo : pneg_hi) >> (pidx & 63u)) & 1u;
 }
 
+// PUNCT value that makes the slot tables read an already interleaved mapper message (stream A,
+// bit j of the symbol) instead of the encoder's output streams
+constexpr int SRC_MESSAGE = 3;
+
 // Bit I of slot word WORD: byte I / NBPSC, constellation index bit t = I % NBPSC (t = 0 is the
 // index MSB: ftw/ftw_ofdm_mapper.cc:262-275 consumes the message MSB first).
 template <int NBPSC, int PUNCT, int WORD, int I, int NA>
@@ -545,6 +551,9 @@ __device__ __forceinline__ uint32_t slot_bit(const uint32_t (&Aw)[NA], const uin
     constexpr int c = SlotCode<4 * WORD + b>::value;
     if constexpr (c < 0) {
         return 0u;
+    } else if constexpr (PUNCT == SRC_MESSAGE) {
+        constexpr int n = NBPSC * c + t;
+        return ((Aw[n >> 5] >> (31 - (n & 31))) & 1u) << (8 * b + NBPSC - 1 - t);
     } else {
         constexpr int p = unpuncture<PUNCT>(deinterleave<NBPSC>(NBPSC * c + t)), n = p >> 1;
         const uint32_t w = (p & 1) ? Bw[n >> 5] : Aw[n >> 5];
@@ -626,6 +635,28 @@ __device__ __forceinline__ void symbol_slots(const uint32_t *U, uint32_t *SI, ui
     }
 }
 
+// The same slot rows from a mapper message held as MSB-first words MW (bit 0 of the message =
+// bit 31 of MW[0]; the 48 SIGNAL bits lead): DATA symbol d occupies message bits
+// 48 + d*N_cbps .. (ftw/ftw_ofdm_mapper.cc:184-260).
+template <int NBPSC>
+__device__ __forceinline__ void message_slots(const uint32_t *MW, uint32_t *SI, uint32_t d0, uint32_t n_sym,
+                                              uint32_t pilot_base, uint64_t pneg_lo, uint64_t pneg_hi, int lane)
+{
+    constexpr int N = 48 * NBPSC;
+    constexpr int NW = (N + 31) / 32;
+    const uint32_t d = d0 + (uint32_t)lane;
+    if (d < n_sym) {
+        const uint32_t b0 = 48u + d * N;
+        const uint32_t w0 = b0 >> 5, o = b0 & 31u;
+        uint32_t Mw[NW];
+#pragma unroll
+        for (int i = 0; i < NW; i++) Mw[i] = __funnelshift_l(MW[w0 + i + 1], MW[w0 + i], o);
+        const uint32_t neg = pilot_negative((pilot_base + 1u + d) % 127u, pneg_lo, pneg_hi);
+        slot_words<NBPSC, SRC_MESSAGE>(Mw, Mw, neg, SI + SLOT_ROW_WORDS * lane,
+                                       std::make_integer_sequence<int, SLOT_ROW_WORDS>{});
+    }
+}
+
 constexpr int ENC_WAVES = 4;
 constexpr int ENC_A_WORDS = 1600;   // natural MPDU (2 zero words + <= 792 words), later the message words
 constexpr int ENC_U_WORDS = MAX_PLCP / 4 + 4;
@@ -674,82 +705,53 @@ k_encode_bits(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads,
 constexpr int TG = 72;   // float2 per symbol in the transposition layout (8 rows x 9)
 constexpr int RS = 88;   // float2 per row in the staging layout
 
-// Second half of a group of 8 consecutive output rows by one wavefront, 8 lanes per row
-// (lane = 8*g + l): 64-point inverse DFT -> cyclic prefix / preamble / gap -> coalesced stores.
-//   type 0 preamble row `pre_row`, 1 OFDM symbol, 2 zero-gap row, 3 no row
-//   x     (type 1) the lane's decimated carriers X[l + 8m], m = 0..7
-//   buf   the wave's LDS area of 8*RS float2; dst = first of the group's `rows_here` rows
-// SYM_ONLY: every row is of type 1 or 3 (the fused kernel copies preamble and gap rows itself).
-template <bool SYM_ONLY>
-__device__ __forceinline__ void ifft64_emit(int type, uint32_t pre_row, v2f (&x)[8], bool any_symbol, int l, int g,
-                                            int lane, v2f *buf, const v2f *s_pre, const v2f *s_tw, bool swap_iq,
-                                            float4 *__restrict__ dst, uint32_t rows_here)
+// A group of up to 8 consecutive OFDM symbol rows by one wavefront, 8 lanes per row
+// (lane = 8*g + l): 64-point inverse DFT -> cyclic prefix -> coalesced stores.
+//   active  the lane's row exists
+//   x       (active) the lane's decimated carriers X[l + 8m], m = 0..7
+//   buf     the wave's LDS area of 8*RS float2; dst = first of the group's `rows_here` rows
+__device__ __forceinline__ void ifft64_emit(bool active, v2f (&x)[8], int l, int g, int lane, v2f *buf,
+                                            const v2f *s_tw, bool swap_iq, float4 *__restrict__ dst,
+                                            uint32_t rows_here)
 {
     SEC("fft1");
     // ---- 64-point inverse DFT as 8 x 8: x[8q+p] = sum_l W8^{lq} W64^{lp} sum_m X[l+8m] W8^{mp}
     // (s_tw holds W64^{lp} times the output scale, so no separate scaling pass is needed)
-    if (any_symbol) {
-        if (type == 1) {
-            idft8(x);
+    if (active) {
+        idft8(x);
 #pragma unroll
-            for (int p = 0; p < 8; p++) x[p] = cmul(x[p], s_tw[8 * p + l]);
+        for (int p = 0; p < 8; p++) x[p] = cmul(x[p], s_tw[8 * p + l]);
 #pragma unroll
-            for (int p = 0; p < 8; p++) buf[g * TG + 9 * p + l] = x[p];
-        }
-        wave_sync();
-        if (type == 1) {
-#pragma unroll
-            for (int i = 0; i < 8; i++) x[i] = buf[g * TG + 9 * l + i];   // lane now plays p = l
-        }
-        wave_sync();
+        for (int p = 0; p < 8; p++) buf[g * TG + 9 * p + l] = x[p];
     }
+    wave_sync();
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) x[i] = buf[g * TG + 9 * l + i];   // lane now plays p = l
+    }
+    wave_sync();
 
     SEC("fft2");
     // ---- the row's 80 samples into the staging area.  Lane l owns samples l + 8i, i = 0..9:
-    // symbol rows: out[o] = x[(o + 48) % 64] (cyclic prefix, examples/ftw_ofdm.py:121-123), so
-    // i = 0,1 repeat q = 6,7 and i >= 2 is q = i - 2; preamble rows copy the table, gap rows are 0.
-    // I/Q exchange (examples/ftw_ofdm.py:155-163) sits in a branch the compiler must keep (the
-    // empty asm): turned into selects it would cost every launch 20 instructions per group.
-    if constexpr (SYM_ONLY) {
-        if (type == 1) {
-            idft8(x);                                                 // x[q] = sample 8q + l
-            if (swap_iq) {
-                asm volatile("");
-#pragma unroll
-                for (int q = 0; q < 8; q++) x[q] = (v2f){x[q].y, x[q].x};
-            }
-#pragma unroll
-            for (int i = 0; i < 10; i++) buf[g * RS + l + 8 * i] = x[(i + 6) & 7];
-        }
-    } else {
-        v2f o10[10];
-        if (type == 1) {
-            idft8(x);
-            o10[0] = x[6];
-            o10[1] = x[7];
-#pragma unroll
-            for (int q = 0; q < 8; q++) o10[q + 2] = x[q];
-        } else if (type == 0) {
-#pragma unroll
-            for (int i = 0; i < 10; i++) o10[i] = s_pre[pre_row * SYM_LEN + l + 8 * i];
-        } else {
-#pragma unroll
-            for (int i = 0; i < 10; i++) o10[i] = (v2f){0.f, 0.f};
-        }
+    // out[o] = x[(o + 48) % 64] (cyclic prefix, examples/ftw_ofdm.py:121-123), so i = 0,1 repeat
+    // q = 6,7 and i >= 2 is q = i - 2.  I/Q exchange (examples/ftw_ofdm.py:155-163) sits in a branch
+    // the compiler must keep (the empty asm): turned into selects it would cost every launch 16
+    // instructions per group.
+    if (active) {
+        idft8(x);                                                     // x[q] = sample 8q + l
         if (swap_iq) {
             asm volatile("");
 #pragma unroll
-            for (int i = 0; i < 10; i++) o10[i] = (v2f){o10[i].y, o10[i].x};
+            for (int q = 0; q < 8; q++) x[q] = (v2f){x[q].y, x[q].x};
         }
 #pragma unroll
-        for (int i = 0; i < 10; i++) buf[g * RS + l + 8 * i] = o10[i];
+        for (int i = 0; i < 10; i++) buf[g * RS + l + 8 * i] = x[(i + 6) & 7];
     }
     wave_sync();
 
     SEC("store");
-    // ---- 8 rows = 5120 contiguous bytes, 16 B per lane per store: always five store
-    // instructions per full group (k_modulate's counted wait relies on that); lanes beyond the
-    // end of the stream are masked, which happens in a last, partial group only
+    // ---- 8 rows = 5120 contiguous bytes, 16 B per lane per store; lanes beyond the last row are
+    // masked, which happens in the last, partial group of a chunk only
     if (rows_here == 8u) {
 #pragma unroll
         for (int i = 0; i < 5; i++) {
@@ -764,211 +766,6 @@ __device__ __forceinline__ void ifft64_emit(int type, uint32_t pre_row, v2f (&x)
                 dst[e] = *reinterpret_cast<const float4 *>(buf + (e / 40) * RS + (e % 40) * 2);
         }
     }
-}
-
-// One group of 8 consecutive output rows from mapper message bits (k_modulate):
-// mapping -> ifft64_emit.
-//   W     the lane's 64 message bits, first wanted bit at bit 63 (bins 8l..8l+7, nb bits each)
-//   kinds 2 bits per bin: 0 null, 1 data, 2 pilot +p, 3 pilot -p; d0 = first data carrier of the lane
-__device__ __forceinline__ void modulate_group(int type, uint32_t pre_row, uint64_t W, uint32_t nb, uint32_t lut_off,
-                                      float pil, uint32_t map_row, float2 *__restrict__ mapped,
-                                      uint32_t kinds, int d0, int l, int g, int lane, float2 *buf_,
-                                      const float2 *s_lut_, const float2 *s_pre_, const float2 *s_tw_,
-                                      bool swap_iq, float4 *__restrict__ dst, uint32_t rows_here)
-{
-    v2f *buf = reinterpret_cast<v2f *>(buf_);
-    const v2f *s_lut = reinterpret_cast<const v2f *>(s_lut_);
-    const bool any_symbol = __ballot(type == 1) != 0ull;
-    v2f x[8];
-
-    SEC("map");
-    if (any_symbol) {
-        // ---- mapper + pilots + carrier map, bins in natural order (transposition layout).
-        // Branch-free per bin: every bin looks up the LUT with the bits at the running offset;
-        // only data bins advance the offset, the others replace the value.
-        if (type == 1) {
-            uint32_t used = 0, nd = 0;
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const uint32_t kind = (kinds >> (2 * i)) & 3u;
-                const uint32_t idx = (uint32_t)((W << used) >> (64u - nb));
-                v2f v = s_lut[lut_off + idx];
-                if (mapped && kind == 1u) mapped[(size_t)map_row * 48u + d0 + nd] = make_float2(v.x, v.y);
-                const bool data = kind == 1u;
-                const float pv = kind == 2u ? pil : (kind == 3u ? -pil : 0.f);
-                v.x = data ? v.x : pv;
-                v.y = data ? v.y : 0.f;
-                used += data ? nb : 0u;
-                nd += data ? 1u : 0u;
-                buf[g * TG + 9 * l + i] = v;
-            }
-        }
-        wave_sync();
-        if (type == 1) {
-#pragma unroll
-            for (int m = 0; m < 8; m++) x[m] = buf[g * TG + l + 9 * m];
-        }
-        wave_sync();
-    }
-    ifft64_emit<false>(type, pre_row, x, any_symbol, l, g, lane, buf, reinterpret_cast<const v2f *>(s_pre_),
-                       reinterpret_cast<const v2f *>(s_tw_), swap_iq, dst, rows_here);
-}
-
-constexpr int MOD_WAVES = 4;
-
-// Row descriptor packed into one register:
-//   bits 0..1   type (0 preamble, 1 symbol, 2 gap, 3 beyond the end)
-//   bits 2..4   bits per carrier       bits 5..9   bit offset of the lane's window in its first dword
-//   bits 10..16 LUT offset             bit 17      pilot polarity is -1
-//   bits 18..19 preamble row index
-__device__ __forceinline__ int cw_type(uint32_t cw) { return (int)(cw & 3u); }
-
-// Decode row `grp*8 + g`: returns the descriptor and the address of the lane's 8-byte message
-// window (src).  d0 = first data carrier among the lane's eight bins.
-template <bool UNIFORM>
-__device__ __forceinline__ uint32_t prepare_row(const PlanParams &P, uint64_t pneg_lo, uint64_t pneg_hi, const uint8_t *msg,
-                                       uint32_t grp, uint32_t n_groups, int g, int d0,
-                                       uint32_t pre_rows, const uint8_t *&src, uint32_t &map_row)
-{
-    src = msg;                     // rows without message bits still load (and ignore) 12 valid bytes
-    map_row = 0;
-    if (grp >= n_groups) return 3u;
-    const uint32_t row = grp * 8u + g;
-    if (row >= P.total_rows) return 3u;
-    uint32_t pkt, r;
-    if (UNIFORM) {
-        pkt = row / P.rows_per_pkt;
-        r = row - pkt * P.rows_per_pkt;
-    } else {
-        pkt = P.group_pkt[grp];
-        while (pkt + 1 < P.n_pkts && row >= P.row_start[pkt + 1]) pkt++;
-        r = row - P.row_start[pkt];
-    }
-    if (r < pre_rows) return 0u | (r << 18);
-    const Pkt k = load_pkt<UNIFORM>(P, pkt);
-    const uint32_t s = r - pre_rows;                                     // symbol index, 0 = SIGNAL
-    if (s > k.n_sym) return 2u;
-    const RegimeInfo ri = regime_info((int)k.regime);
-    const uint32_t nb = s == 0 ? 1u : (uint32_t)ri.n_bpsc;               // ftw/ftw_ofdm_mapper.cc:184-191
-    const uint32_t lut_off = s == 0 ? (uint32_t)LUT_PM1 : (uint32_t)ri.lut_off;
-    const uint32_t bit0 = (s == 0 ? 0u : 48u + (s - 1u) * ri.n_cbps) + (uint32_t)d0 * nb;
-    // up to 7 carriers x 6 bits + 7 bits of misalignment fit in 64 bits
-    // (fetched as three ALIGNED dwords: unaligned 8-byte loads are several times slower)
-    const uint8_t *first = msg + k.msg_off + (bit0 >> 3);
-    const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(first) & 3u);
-    src = first - mis;
-    const uint32_t pidx = (k.pilot_base + s) % 127u;                     // ftw/ftw_ofdm_pilot_cc.cc:116
-    // (selects instead of indexing: a dynamically indexed kernel-argument array becomes a
-    //  vector-memory load, and with it a wait for every store in flight)
-    const uint32_t neg = (uint32_t)((pidx < 64u ? pneg_lo : pneg_hi) >> (pidx & 63u)) & 1u;
-    map_row = k.sym_off + s;
-    return 1u | (nb << 2) | ((8u * mis + (bit0 & 7u)) << 5) | (lut_off << 10) | (neg << 17);
-}
-
-template <bool UNIFORM>
-__global__ void __launch_bounds__(64 * MOD_WAVES)
-k_modulate(PlanParams P, DevTables T, const uint8_t *__restrict__ msg, float2 *__restrict__ mapped,
-           float2 *__restrict__ iq)
-{
-    __shared__ float2 s_lut[LUT_SIZE];
-    __shared__ float2 s_pre[PRE_ROWS * SYM_LEN];
-    __shared__ float2 s_tw[64];
-    // Per-wave LDS area, used three times per iteration with two layouts chosen so that every
-    // access pattern below is bank-conflict free (ds_*_b64: 64 banks for reads, 32 for writes):
-    //   transposition layout: element (a,b) of symbol g at TG*g + 9*a + b    (rows of 8 padded to 9)
-    //   staging layout      : sample o of row g at RS*g + o                  (rows of 80 padded to 88)
-    __shared__ __align__(16) float2 s_buf[MOD_WAVES][8 * RS];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float amp = P.amp;
-    // 1/sqrt(64) (examples/ftw_ofdm.py:126) is a power of two: (x*0.125)*amp == x*(0.125*amp)
-    const float scale = 0.125f * amp;
-    for (int i = tid; i < LUT_SIZE; i += 64 * MOD_WAVES) s_lut[i] = T.lut[i];
-    for (int i = tid; i < PRE_ROWS * SYM_LEN; i += 64 * MOD_WAVES) {
-        float2 v = T.preamble[i];                         // pu:508 literals as float32 ...
-        s_pre[i] = make_float2(v.x * amp, v.y * amp);     // ... times tx_amplitude
-    }
-    // twiddles W64^{l*p} of the 8x8 decomposition, entry 8*p + l (lanes of a symbol read 8
-    // consecutive entries, the 8 symbols of a wave read the same ones)
-    for (int i = tid; i < 64; i += 64 * MOD_WAVES) {
-        const float2 w = T.tw64[((i & 7) * (i >> 3)) & 63];
-        s_tw[i] = make_float2(w.x * scale, w.y * scale);
-    }
-    __syncthreads();
-
-    const int l = lane & 7, g = lane >> 3;
-    float2 *buf = s_buf[wave];
-
-    // the lane's own eight consecutive bins 8l..8l+7 (mapping stage)
-    // kinds: 2 bits per bin -- 0 null, 1 data, 2 pilot +p, 3 pilot -p; d0 = first data carrier
-    uint32_t kinds = 0;
-    int d0 = -1;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int c = bin_code(8 * l + i);
-        if (c >= 0 && d0 < 0) d0 = c;
-        kinds |= (uint32_t)(c >= 0 ? 1 : (c == -1 ? 0 : (c == -2 ? 2 : 3))) << (2 * i);
-    }
-
-    // pilot polarity mask pinned in scalar registers
-    uint64_t pneg_lo = T.pilot_neg[0] | ((uint64_t)T.pilot_neg[1] << 32);
-    uint64_t pneg_hi = T.pilot_neg[2] | ((uint64_t)T.pilot_neg[3] << 32);
-    asm volatile("" : "+s"(pneg_lo), "+s"(pneg_hi));
-
-    const uint32_t pre_rows = (P.flags & OFDMTX_F_PREAMBLE) ? PRE_ROWS : 0;
-    const uint32_t n_groups = (P.total_rows + 7u) / 8u;
-    const bool swap_iq = (P.flags & OFDMTX_F_SWAPIQ) != 0;
-
-    // Pipeline over groups: the message window of group i+1 is requested one iteration ahead.
-    // Loads and stores share the vector-memory counter and retire in issue order, but hipcc
-    // waits for vmcnt(0) -- i.e. for every store in flight -- whenever it sees a loaded value used
-    // while stores are pending.  The window load is therefore issued from inline asm, invisible
-    // to that pass, and retired by a counted wait: between the load of group i+1 and its first
-    // use exactly the five IQ stores of group i are issued (tap stores, if any, only add to
-    // that), so "vmcnt(5)" is the load's completion.  LOAD_WINDOW / WAIT_WINDOW are the only
-    // places that touch the pending registers.
-#define LOAD_WINDOW(dst, ptr) asm volatile("global_load_dwordx3 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
-#define WAIT_WINDOW(dst) asm volatile("s_waitcnt vmcnt(5)" : "+v"(dst) : : "memory")
-    const uint32_t grp_stride = gridDim.x * MOD_WAVES;
-    const uint32_t grp0 = blockIdx.x * MOD_WAVES + wave;
-    const uint8_t *src;
-    typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
-    // 64 message bits starting at the lane's first wanted bit (that bit at bit 63)
-    auto window = [](u32x3 raw, uint32_t cw) {
-        const uint32_t sh = (cw >> 5) & 31u;
-        const uint32_t b0 = __builtin_bswap32(raw.x), b1 = __builtin_bswap32(raw.y), b2 = __builtin_bswap32(raw.z);
-        return ((uint64_t)__funnelshift_l(b1, b0, sh) << 32) | __funnelshift_l(b2, b1, sh);
-    };
-    u32x3 raw_n;                                          // window of group i+1, in flight
-    uint32_t map_c, map_n;
-    uint32_t cw_c = prepare_row<UNIFORM>(P, pneg_lo, pneg_hi, msg, grp0, n_groups, g, d0, pre_rows, src, map_c);
-    LOAD_WINDOW(raw_n, src);
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw_n) : : "memory");
-    uint64_t W_c = window(raw_n, cw_c);
-    uint32_t cw_n = prepare_row<UNIFORM>(P, pneg_lo, pneg_hi, msg, grp0 + grp_stride, n_groups, g, d0, pre_rows, src, map_n);
-    LOAD_WINDOW(raw_n, src);
-
-    for (uint32_t grp = grp0; grp < n_groups; grp += grp_stride) {
-        const int type = cw_type(cw_c);
-
-        modulate_group(type, cw_c >> 18, W_c, (cw_c >> 2) & 7u, (cw_c >> 10) & 127u,
-                       (cw_c >> 17) & 1u ? -1.f : 1.f, map_c, mapped, kinds, d0, l, g, lane, buf, s_lut, s_pre,
-                       s_tw, swap_iq, reinterpret_cast<float4 *>(iq + (size_t)grp * 8u * SYM_LEN),
-                       P.total_rows - grp * 8u < 8u ? P.total_rows - grp * 8u : 8u);
-
-        // ---- rotate the pipeline: retire the window of the next group, request the one after
-        if (grp + grp_stride < n_groups) {
-            WAIT_WINDOW(raw_n);
-            cw_c = cw_n;
-            map_c = map_n;
-            W_c = window(raw_n, cw_n);
-            cw_n = prepare_row<UNIFORM>(P, pneg_lo, pneg_hi, msg, grp + 2u * grp_stride, n_groups, g, d0, pre_rows, src, map_n);
-            LOAD_WINDOW(raw_n, src);
-        }
-        wave_sync();
-    }
-#undef LOAD_WINDOW
-#undef WAIT_WINDOW
 }
 
 // ======================================================================================
@@ -993,14 +790,18 @@ constexpr int TX_B_WORDS = 8 * RS * 2;
 
 // (second launch bound = 4 waves per SIMD: caps the kernel at 128 VGPRs; uncapped, hipcc spends
 //  ~250 on the encoder's bit table and halves the occupancy of the whole kernel)
-template <bool UNIFORM, int REGIME>
+//
+// FROM_MSG: the input is not the payloads but the mapper messages k_encode_bits wrote (the
+// two-kernel path, with its taps): the message words take the place of the scrambled words and
+// the slot rows come from message_slots; `mapped` (optional) receives the mapper block's output.
+template <bool UNIFORM, int REGIME, bool FROM_MSG>
 __global__ void __launch_bounds__(64 * TX_WAVES, 4)
-k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads, float2 *__restrict__ iq,
-     uint32_t a_words, uint32_t u_off, uint32_t wave_words)
+k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ in, float2 *__restrict__ mapped,
+     float2 *__restrict__ iq, uint32_t a_words, uint32_t u_off, uint32_t wave_words)
 {
     extern __shared__ __align__(16) uint32_t s_dyn[];
-    __shared__ uint32_t s_crc[1024];
-    __shared__ uint32_t s_scr[128];
+    __shared__ uint32_t s_crc[FROM_MSG ? 1 : 1024];
+    __shared__ uint32_t s_scr[FROM_MSG ? 1 : 128];
     __shared__ float2 s_lut[LUT_SIZE];
     __shared__ __align__(16) float2 s_pre[PRE_ROWS * SYM_LEN];
     __shared__ float2 s_tw[64];
@@ -1032,8 +833,10 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads, float2 *__
     }
     // 1/sqrt(64) (examples/ftw_ofdm.py:126) is a power of two: (x*0.125)*amp == x*(0.125*amp)
     const float scale = 0.125f * amp;
-    for (int i = tid; i < 127; i += 64 * TX_WAVES) s_scr[i] = T.scr_word[i];
-    for (int i = tid; i < 1024; i += 64 * TX_WAVES) s_crc[i] = T.crc_tab[i];
+    if constexpr (!FROM_MSG) {
+        for (int i = tid; i < 127; i += 64 * TX_WAVES) s_scr[i] = T.scr_word[i];
+        for (int i = tid; i < 1024; i += 64 * TX_WAVES) s_crc[i] = T.crc_tab[i];
+    }
     for (int i = tid; i < LUT_SIZE; i += 64 * TX_WAVES) s_lut[i] = T.lut[i];
     for (int i = tid; i < PRE_ROWS * SYM_LEN; i += 64 * TX_WAVES) {
         const float2 v = T.preamble[i];                   // pu:508 literals as float32 times tx_amplitude,
@@ -1065,7 +868,17 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads, float2 *__
         float4 *out = reinterpret_cast<float4 *>(iq + row0 * SYM_LEN);
         const uint32_t sym_rows = k.n_sym + 1u;                    // SIGNAL + DATA symbols
 
-        scramble_packet(k, ri, T, payloads, A, U, s_crc, s_scr, lane, nullptr, nullptr);
+        if constexpr (FROM_MSG) {
+            // message bytes -> MSB-first words (the plan keeps messages 16-byte aligned, with slack
+            // behind the last one); two zero words behind them for the funnel shifts
+            const uint32_t msg_len = 6u + k.n_sym * (uint32_t)ri.n_cbps / 8u;
+            const uint32_t n_mw = (msg_len + 3u) / 4u;
+            const uint32_t *mp = reinterpret_cast<const uint32_t *>(in + k.msg_off);
+            for (uint32_t w = lane; w < n_mw + 2u; w += 64) U[w] = w < n_mw ? __builtin_bswap32(mp[w]) : 0u;
+            wave_sync();
+        } else {
+            scramble_packet(k, ri, T, in, A, U, s_crc, s_scr, lane, nullptr, nullptr);
+        }
 
         SEC("copy");
         // ---- preamble rows (ftw/ftw_ofdm_preamble.cc:79-95) and zero gap (ftw/ftw_zerogap.cc:88-99)
@@ -1086,10 +899,15 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads, float2 *__
             SEC("e4_signal");
             // ---- SIGNAL row: 48 coded bits (N = 48: first permutation only, pu:245-249), BPSK
             if (d0 == 0) {
-                const uint32_t t = 63u - lane;            // ballot bit `lane` = carrier 63 - lane
-                uint32_t bi = 0;
-                if (t < 48u) bi = coded_bit(U, 16u * (t % 3u) + t / 3u);
-                const unsigned long long mi = __ballot(bi);
+                unsigned long long mi;                    // bit 63 - d = interleaved SIGNAL bit d
+                if constexpr (FROM_MSG) {
+                    mi = ((unsigned long long)U[0] << 32) | U[1];
+                } else {
+                    const uint32_t t = 63u - lane;        // ballot bit `lane` = carrier 63 - lane
+                    uint32_t bi = 0;
+                    if (t < 48u) bi = coded_bit(U, 16u * (t % 3u) + t / 3u);
+                    mi = __ballot(bi);
+                }
                 const uint32_t neg0 = pilot_negative(k.pilot_base % 127u, pneg_lo, pneg_hi);
                 if (lane < 4 * SLOT_ROW_WORDS) {
                     const int sig_c = s_sigc[lane];
@@ -1101,15 +919,25 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads, float2 *__
             SEC("e5_data");
             // ---- DATA rows.  REGIME != 0: the batch has one regime, known when the kernel was
             // chosen, and only that instantiation is compiled in; 0 dispatches per packet.
-            switch (REGIME ? (uint32_t)REGIME : k.regime) {
-            case 1: symbol_slots<1, 0>(U, SI + SLOT_ROW_WORDS * shift, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
-            case 2: symbol_slots<1, 1>(U, SI + SLOT_ROW_WORDS * shift, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
-            case 3: symbol_slots<2, 0>(U, SI + SLOT_ROW_WORDS * shift, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
-            case 4: symbol_slots<2, 1>(U, SI + SLOT_ROW_WORDS * shift, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
-            case 5: symbol_slots<4, 0>(U, SI + SLOT_ROW_WORDS * shift, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
-            case 6: symbol_slots<4, 1>(U, SI + SLOT_ROW_WORDS * shift, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
-            case 7: symbol_slots<6, 2>(U, SI + SLOT_ROW_WORDS * shift, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
-            default: symbol_slots<6, 1>(U, SI + SLOT_ROW_WORDS * shift, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
+            uint32_t *rows = SI + SLOT_ROW_WORDS * shift;
+            if constexpr (FROM_MSG) {
+                switch (ri.n_bpsc) {
+                case 1: message_slots<1>(U, rows, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
+                case 2: message_slots<2>(U, rows, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
+                case 4: message_slots<4>(U, rows, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
+                default: message_slots<6>(U, rows, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
+                }
+            } else {
+                switch (REGIME ? (uint32_t)REGIME : k.regime) {
+                case 1: symbol_slots<1, 0>(U, rows, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
+                case 2: symbol_slots<1, 1>(U, rows, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
+                case 3: symbol_slots<2, 0>(U, rows, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
+                case 4: symbol_slots<2, 1>(U, rows, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
+                case 5: symbol_slots<4, 0>(U, rows, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
+                case 6: symbol_slots<4, 1>(U, rows, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
+                case 7: symbol_slots<6, 2>(U, rows, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
+                default: symbol_slots<6, 1>(U, rows, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
+                }
             }
             wave_sync();
 
@@ -1125,9 +953,9 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads, float2 *__
             const uint32_t row_base = d0 == 0 ? 0u : d0 + 1u;           // first output row of the chunk
             for (uint32_t r0 = 0; r0 < rows_chunk; r0 += 8u) {
                 SEC("map");
-                const int type = r0 + (uint32_t)g < rows_chunk ? 1 : 3;
+                const bool active = r0 + (uint32_t)g < rows_chunk;
                 v2f x[8];
-                if (type == 1) {
+                if (active) {
                     const uint32_t *rp = SI + SLOT_ROW_WORDS * r0 + slot_word0;
                     const uint32_t d0 = rp[0], d1 = rp[1], d2 = rp[2];
                     const uint32_t wlo = __builtin_amdgcn_alignbyte(d1, d0, slot_sh);
@@ -1140,9 +968,20 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads, float2 *__
                         x[m + 4] = lut[(s_hi >> (8 * m)) & 0xFFu];
                     }
                 }
-                ifft64_emit<true>(type, 0u, x, true, l, g, lane_r, buf, nullptr, reinterpret_cast<const v2f *>(s_tw),
-                                  swap_iq, out + (size_t)(row_base + r0) * (SYM_LEN / 2),
-                                  rows_chunk - r0 < 8u ? rows_chunk - r0 : 8u);
+                if constexpr (FROM_MSG) {
+                    // tap: the mapper block's 48 values per symbol, in carrier order
+                    if (mapped && active) {
+                        float2 *mrow = mapped + ((size_t)k.sym_off + row_base + r0 + (uint32_t)g) * 48u;
+#pragma unroll
+                        for (int m = 0; m < 8; m++) {
+                            const int c = bin_code(l + 8 * m);
+                            if (c >= 0) mrow[c] = make_float2(x[m].x, x[m].y);
+                        }
+                    }
+                }
+                ifft64_emit(active, x, l, g, lane_r, buf, reinterpret_cast<const v2f *>(s_tw), swap_iq,
+                            out + (size_t)(row_base + r0) * (SYM_LEN / 2),
+                            rows_chunk - r0 < 8u ? rows_chunk - r0 : 8u);
                 SEC("end");
                 wave_sync();
             }
@@ -1358,7 +1197,8 @@ static inline uint32_t tx_words_for(const ofdmtx_pkt_info &pi)
 }
 static inline uint32_t tx_u_words_for(const ofdmtx_pkt_info &pi)
 {
-    return (((uint32_t)(pi.plcp_len + 3) / 4 + 4) + 3u) & ~3u;
+    const uint32_t plcp = (uint32_t)(pi.plcp_len + 3) / 4 + 4, msg = (uint32_t)(pi.msg_len + 3) / 4 + 4;
+    return ((plcp > msg ? plcp : msg) + 3u) & ~3u;
 }
 
 static void plan_common(ofdmtx_plan *pl, ofdmtx_ctx *ctx, uint64_t n, int pilot_mode,
@@ -1622,56 +1462,41 @@ int ofdmtx_encode_bits(ofdmtx_ctx *ctx, const ofdmtx_plan *pl, const uint8_t *d_
     return OFDMTX_OK;
 }
 
-int ofdmtx_modulate(ofdmtx_ctx *ctx, const ofdmtx_plan *pl, const uint8_t *d_msg, float *d_mapped,
-                    float *d_iq, void *stream)
-{
-    if (!ctx || !pl || pl->ctx != ctx || !d_msg || !d_iq) return OFDMTX_EINVAL;
-    if (pl->pp.total_rows == 0) return OFDMTX_OK;
-    HIPCHK(hipSetDevice(ctx->device));
-    const uint64_t groups = ((uint64_t)pl->pp.total_rows + 7) / 8;
-    const int grid = grid_for(ctx, groups, MOD_WAVES, 8);
-    hipStream_t st = (hipStream_t)stream;
-    if (pl->pp.uniform)
-        hipLaunchKernelGGL(k_modulate<true>, dim3(grid), dim3(64 * MOD_WAVES), 0, st, pl->pp,
-                           ctx->tables(), d_msg, reinterpret_cast<float2 *>(d_mapped),
-                           reinterpret_cast<float2 *>(d_iq));
-    else
-        hipLaunchKernelGGL(k_modulate<false>, dim3(grid), dim3(64 * MOD_WAVES), 0, st, pl->pp,
-                           ctx->tables(), d_msg, reinterpret_cast<float2 *>(d_mapped),
-                           reinterpret_cast<float2 *>(d_iq));
-    HIPCHK(hipGetLastError());
-    return OFDMTX_OK;
-}
+}  // extern "C"
 
-int ofdmtx_tx(ofdmtx_ctx *ctx, const ofdmtx_plan *pl, const uint8_t *d_payloads, uint8_t *d_work,
-              float *d_iq, void *stream)
+// Launch of the wave-per-packet kernel for either input (payloads or mapper messages).
+template <bool FROM_MSG>
+static int launch_tx(ofdmtx_ctx *ctx, const ofdmtx_plan *pl, const uint8_t *d_in, float2 *mapped, float2 *iq,
+                     hipStream_t st)
 {
-    (void)d_work;   // the fused kernel keeps the mapper messages in LDS
-    if (!ctx || !pl || pl->ctx != ctx || !d_iq) return OFDMTX_EINVAL;
-    if (!d_payloads && pl->sizes.payload_bytes) return OFDMTX_EINVAL;
-    if (pl->pp.n_pkts == 0) return OFDMTX_OK;
-    HIPCHK(hipSetDevice(ctx->device));
-    // one chunk: U shares the staging area; several chunks: U needs a region of its own
+    // one chunk: the scrambled / message words share the staging area; several chunks: they need
+    // a region of their own
     const bool one_chunk = pl->max_sym_rows <= 65u;
     const uint32_t a_words = pl->tx_a_words;
     const uint32_t u_off = one_chunk ? a_words : a_words + (uint32_t)TX_B_WORDS;
     const uint32_t wave_words = a_words + (uint32_t)TX_B_WORDS + (one_chunk ? 0u : pl->tx_u_words);
     const size_t lds = (size_t)TX_WAVES * wave_words * sizeof(uint32_t);
     const int grid = grid_for(ctx, pl->pp.n_pkts, TX_WAVES, 2);
-    hipStream_t st = (hipStream_t)stream;
     const PlanParams &pp = pl->pp;
     const DevTables tab = ctx->tables();
-    float2 *iq = reinterpret_cast<float2 *>(d_iq);
     // a workgroup may use more than the default 64 KiB of LDS only after asking for it
 #define LAUNCH_TX(U_, R_)                                                                            \
     do {                                                                                             \
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tx<U_, R_>),                    \
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tx<U_, R_, FROM_MSG>),          \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));           \
-        hipLaunchKernelGGL((k_tx<U_, R_>), dim3(grid), dim3(64 * TX_WAVES), lds, st, pp, tab,        \
-                           d_payloads, iq, a_words, u_off, wave_words);                              \
+        hipLaunchKernelGGL((k_tx<U_, R_, FROM_MSG>), dim3(grid), dim3(64 * TX_WAVES), lds, st, pp,   \
+                           tab, d_in, mapped, iq, a_words, u_off, wave_words);                       \
     } while (0)
     if (!pp.uniform) {
         LAUNCH_TX(false, 0);
+    } else if (FROM_MSG) {
+        // the message path does not depend on the code rate: one instantiation per constellation
+        switch (regime_info((int)pp.regime).n_bpsc) {
+        case 1: LAUNCH_TX(true, 1); break;
+        case 2: LAUNCH_TX(true, 3); break;
+        case 4: LAUNCH_TX(true, 5); break;
+        default: LAUNCH_TX(true, 8); break;
+        }
     } else {
         switch (pp.regime) {
         case 1: LAUNCH_TX(true, 1); break;
@@ -1687,6 +1512,29 @@ int ofdmtx_tx(ofdmtx_ctx *ctx, const ofdmtx_plan *pl, const uint8_t *d_payloads,
 #undef LAUNCH_TX
     HIPCHK(hipGetLastError());
     return OFDMTX_OK;
+}
+
+extern "C" {
+
+int ofdmtx_modulate(ofdmtx_ctx *ctx, const ofdmtx_plan *pl, const uint8_t *d_msg, float *d_mapped,
+                    float *d_iq, void *stream)
+{
+    if (!ctx || !pl || pl->ctx != ctx || !d_msg || !d_iq) return OFDMTX_EINVAL;
+    if (pl->pp.n_pkts == 0) return OFDMTX_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    return launch_tx<true>(ctx, pl, d_msg, reinterpret_cast<float2 *>(d_mapped), reinterpret_cast<float2 *>(d_iq),
+                           (hipStream_t)stream);
+}
+
+int ofdmtx_tx(ofdmtx_ctx *ctx, const ofdmtx_plan *pl, const uint8_t *d_payloads, uint8_t *d_work,
+              float *d_iq, void *stream)
+{
+    (void)d_work;   // the fused kernel keeps the mapper messages in LDS
+    if (!ctx || !pl || pl->ctx != ctx || !d_iq) return OFDMTX_EINVAL;
+    if (!d_payloads && pl->sizes.payload_bytes) return OFDMTX_EINVAL;
+    if (pl->pp.n_pkts == 0) return OFDMTX_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    return launch_tx<false>(ctx, pl, d_payloads, nullptr, reinterpret_cast<float2 *>(d_iq), (hipStream_t)stream);
 }
 
 }  // extern "C"
