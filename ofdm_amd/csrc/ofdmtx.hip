@@ -92,7 +92,6 @@ struct PlanParams {
     // ragged batches
     const PktRec *recs;
     const uint32_t *row_start;    // n_pkts + 1
-    const uint32_t *group_pkt;    // packet holding the first row of every 8-row group
     uint32_t total_rows;
     uint32_t flags;
     float amp;
@@ -1020,7 +1019,6 @@ struct ofdmtx_plan {
     std::vector<uint32_t> plcp_len, msg_len;
     PktRec *d_recs;
     uint32_t *d_row_start;
-    uint32_t *d_group_pkt;
     ofdmtx_pkt_info uni;   // uniform geometry
     uint32_t tx_a_words;   // LDS words per wave the fused kernel needs for the largest packet (first region)
     uint32_t tx_u_words;   // ... for the scrambled words of the longest packet
@@ -1213,7 +1211,6 @@ static void plan_common(ofdmtx_plan *pl, ofdmtx_ctx *ctx, uint64_t n, int pilot_
     pl->pp.amp = amp;
     pl->d_recs = nullptr;
     pl->d_row_start = nullptr;
-    pl->d_group_pkt = nullptr;
 }
 
 int ofdmtx_plan_uniform(ofdmtx_ctx *ctx, uint64_t n_pkts, int regime, uint32_t payload_len,
@@ -1335,26 +1332,13 @@ int ofdmtx_plan_ragged(ofdmtx_ctx *ctx, uint64_t n_pkts, const uint8_t *regimes,
     sz.n_rows = rows;
     sz.n_samples = rows * SYM_LEN;
 
-    // packet of the first row of every 8-row group
-    const uint64_t n_groups = (rows + 7) / 8;
-    std::vector<uint32_t> group_pkt(n_groups ? n_groups : 1);
-    uint64_t p = 0;
-    for (uint64_t gidx = 0; gidx < n_groups; gidx++) {
-        const uint64_t row = gidx * 8;
-        while (p + 1 < n_pkts && row >= pl->row_start[p + 1]) p++;
-        group_pkt[gidx] = (uint32_t)p;
-    }
     hipError_t e = hipSetDevice(ctx->device);
     if (e == hipSuccess) e = hipMalloc(&pl->d_recs, (n_pkts ? n_pkts : 1) * sizeof(PktRec));
     if (e == hipSuccess) e = hipMalloc(&pl->d_row_start, (n_pkts + 1) * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(&pl->d_group_pkt, group_pkt.size() * sizeof(uint32_t));
     if (e == hipSuccess && n_pkts)
         e = hipMemcpy(pl->d_recs, pl->recs.data(), n_pkts * sizeof(PktRec), hipMemcpyHostToDevice);
     if (e == hipSuccess)
         e = hipMemcpy(pl->d_row_start, pl->row_start.data(), (n_pkts + 1) * sizeof(uint32_t),
-                      hipMemcpyHostToDevice);
-    if (e == hipSuccess)
-        e = hipMemcpy(pl->d_group_pkt, group_pkt.data(), group_pkt.size() * sizeof(uint32_t),
                       hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         ofdmtx_g_last_hip = (int)e;
@@ -1363,7 +1347,6 @@ int ofdmtx_plan_ragged(ofdmtx_ctx *ctx, uint64_t n_pkts, const uint8_t *regimes,
     }
     pp.recs = pl->d_recs;
     pp.row_start = pl->d_row_start;
-    pp.group_pkt = pl->d_group_pkt;
     *out = pl;
     return OFDMTX_OK;
 }
@@ -1374,7 +1357,6 @@ int ofdmtx_plan_destroy(ofdmtx_plan *pl)
     (void)hipSetDevice(pl->ctx->device);
     if (pl->d_recs) (void)hipFree(pl->d_recs);
     if (pl->d_row_start) (void)hipFree(pl->d_row_start);
-    if (pl->d_group_pkt) (void)hipFree(pl->d_group_pkt);
     delete pl;
     return OFDMTX_OK;
 }

@@ -67,7 +67,7 @@ def main():
     msg = plan.alloc_msg()
     ms_e = timed(lambda: plan.encode_bits(payloads, out=msg), a.steps)
     ms_m = timed(lambda: plan.modulate(msg, out=iq), a.steps)
-    line("mixed-rate ragged batch, mapper messages -> IQ (k_modulate)", ms_m, plan.msg_bytes + plan.n_samples * 8,
+    line("mixed-rate ragged batch, mapper messages -> IQ (k_tx, message input)", ms_m, plan.msg_bytes + plan.n_samples * 8,
          plan.n_samples, {"packets": n, "k_encode_bits_ms": ms_e})
     del iq, msg, payloads, plan
 

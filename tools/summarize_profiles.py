@@ -33,7 +33,9 @@ if os.path.exists(b):
 
 
 def short(name):
-    for k in ("k_tx", "k_modulate", "k_encode_bits", "k_raw_modulate"):
+    if "k_tx" in name:      # k_tx<UNIFORM, REGIME, FROM_MSG>: the message-input instantiation is its own line
+        return "k_tx_msg" if name.split(">(")[0].rstrip().endswith("true") else "k_tx"
+    for k in ("k_encode_bits", "k_raw_modulate"):
         if k in name:
             return k
     return None
