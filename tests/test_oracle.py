@@ -173,3 +173,23 @@ def test_errors_follow_the_reference():
     o.ftw_make(b"x" * 3140, "1", 4.0)
     with pytest.raises(KeyError):
         o.get_info(b"", "9", 4.0)                # reference: UnboundLocalError (no else branch :39-78)
+
+
+# ---- third restatement (per-bit Python, reference-shaped control flow) against the numpy oracle
+
+@pytest.mark.parametrize("regime", [str(r) for r in range(1, 9)])
+def test_per_bit_restatement_agrees(regime):
+    from oracle import ftw_pybits as pb
+    rng = np.random.default_rng(40 + int(regime))
+    for n, t in ((0, 4.0), (1, 4.0), (37, 8.0), (100, 4.0), (333, 160.0)):
+        payload = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        a = pb.encode_bits(payload, regime, t)
+        b = o.encode_bits(payload, regime, t)
+        for k in ("plcp", "scrambled", "coded", "interleaved"):
+            assert a[k] == b[k], (k, n)
+        assert a["Length"] == b["Length"] and a["N_sym"] == b["info"]["N_sym"]
+
+
+def test_per_bit_lfsr_is_the_reference_sequence():
+    from oracle import ftw_pybits as pb
+    assert pb.lfsr_sequence() == list(o.tables().scrambling_seq)
