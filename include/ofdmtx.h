@@ -216,6 +216,23 @@ int ofdmtx_raw_plan_get_sizes(const ofdmtx_raw_plan *plan, ofdmtx_raw_sizes *out
 int ofdmtx_raw_modulate(ofdmtx_ctx *ctx, const ofdmtx_raw_plan *plan, const float *d_data,
                         float *d_mapped, float *d_iq, void *stream);
 
+/* rawofdm's bit chain in front of its mapper: qam_tx of rawofdm/src/python/raw_qam.py:76-102, i.e.
+ * the blocks raw.conv_punc(framebytes, framebytes+1) (one zero byte of padding per frame),
+ * raw.conv_enc() (rawofdm/src/lib/qam/raw_conv.cc:33-55; K = 7, polynomials {121, 91} of
+ * rawofdm/src/lib/spiral/defs.h:3-7), raw.conv_punc(nc, np) (raw_conv.cc:141-163: the first np of
+ * every nc coded bits), raw.intrlv_bit(ncarriers, qambits, False) (raw_intrlv.cc:14-76) and
+ * raw.qam_enc(qambits) (raw_qam.cc:63-74,113-150).  (qambits, nc, np) as in the `bitrates` table
+ * of raw_qam.py:19-28.
+ * ofdmtx_raw_framebytes: data bytes per frame of `size` = ncarriers*nsymbols complex values
+ * (raw_qam.py:30-37 minus the padding byte); OFDMTX_ESHAPE where the reference's assert fails.
+ * ofdmtx_raw_qam_tx: d_bytes = n_frames x framebytes bytes -> d_out = n_frames x nsymbols x
+ * ncarriers complex64, the input of ofdmtx_raw_modulate.  BPSK values have imaginary part 0 (the
+ * reference leaves that float unwritten). */
+int ofdmtx_raw_framebytes(int qambits, int nc, int np, uint64_t size, uint32_t *out);
+int ofdmtx_raw_qam_tx(ofdmtx_ctx *ctx, int qambits, int nc, int np, uint32_t ncarriers,
+                      uint32_t nsymbols, const uint8_t *d_bytes, uint64_t n_frames, float *d_out,
+                      void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -253,6 +253,70 @@ int launch_raw_n(const ofdmtx_ctx *ctx, const RawParams &rp, const float2 *data,
     }
 }
 
+// -----------------------------------------------------------------------------------------
+// TX bit chain in front of the mapper (rawofdm/src/python/raw_qam.py:76-102): per frame of
+// frame_bytes bytes: one zero byte appended (conv_punc(framebytes, framebytes + 1)), K = 7
+// rate-1/2 encoder, puncturing (the first np of every nc coded bits), bit interleaver per OFDM
+// symbol, Gray QAM.  One thread per output carrier value walks the chain backwards for each of
+// its bits: interleaved position -> punctured index -> coded index -> a 7-bit window of the
+// frame's bytes.  Frames are independent: the zero byte returns the encoder to state 0.
+struct QamTxParams {
+    uint32_t frame_bytes;      // data bytes per frame (without the padding byte)
+    uint32_t ncarriers, nsymbols, qambits, nc, np;
+    uint32_t cbps;             // qambits * ncarriers
+    uint64_t n_values;         // n_frames * nsymbols * ncarriers
+    float scale;               // PAM level spacing / 2 (rawofdm/src/lib/qam/raw_qam.cc:39-52)
+};
+
+// rawofdm/src/lib/spiral/config.h + defs.h:3-7: CODE 121-91, K = 7, POLYS {121, 91} (decimal);
+// rawofdm/src/lib/qam/raw_conv.cc:46-51: newest bit at the register's LSB, first polynomial first
+__device__ __forceinline__ uint32_t raw_coded_bit(const uint8_t *frame, uint32_t frame_bytes, uint32_t c)
+{
+    const uint32_t n = c >> 1;                               // input bit index inside the padded frame
+    // bits n-6 .. n as a window, bit d = u[n-d]; bytes past the data are the zero padding
+    const int32_t b1 = (int32_t)(n >> 3), b0 = b1 - 1;
+    const uint32_t hi = b0 >= 0 && (uint32_t)b0 < frame_bytes ? frame[b0] : 0u;
+    const uint32_t lo = (uint32_t)b1 < frame_bytes ? frame[b1] : 0u;
+    const uint32_t two = (hi << 8) | lo;                     // u[8*b0 ..] MSB first
+    const uint32_t sh = 7u - (n & 7u);                       // u[n] sits at bit sh of `two`
+    const uint32_t reg = (two >> sh) & 0x7Fu;                // bit 0 = u[n], bit d = u[n-d]
+    return __popc(reg & ((c & 1u) ? 91u : 121u)) & 1u;
+}
+
+__global__ void __launch_bounds__(256) k_raw_qam_tx(QamTxParams Q, const uint8_t *__restrict__ data,
+                                                    float2 *__restrict__ out)
+{
+    const uint64_t o = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (o >= Q.n_values) return;
+    const uint32_t per_frame = Q.ncarriers * Q.nsymbols;
+    const uint64_t f = o / per_frame;
+    const uint32_t r = (uint32_t)(o - f * per_frame), sym = r / Q.ncarriers, car = r - sym * Q.ncarriers;
+    const uint8_t *frame = data + f * Q.frame_bytes;
+    const uint32_t s = Q.qambits / 2u > 1u ? Q.qambits / 2u : 1u, col = Q.cbps / 16u;
+    const uint32_t axis_bits = Q.qambits == 1u ? 1u : Q.qambits / 2u;
+    float lv[2] = {0.f, 0.f};
+    for (uint32_t a = 0; a * axis_bits < Q.qambits; a++) {
+        int pt = 0, flip = 1;                                // rawofdm/src/lib/qam/raw_qam.cc:63-74
+        for (uint32_t t = 0; t < axis_bits; t++) {
+            const uint32_t j = car * Q.qambits + a * axis_bits + t;     // position in the interleaved symbol
+            // invert rawofdm/src/lib/qam/raw_intrlv.cc:22-30: j = s*(i/s) + (i + cbps - 16*i/cbps) % s
+            uint32_t i = 0;
+            for (uint32_t q = 0; q < s; q++) {
+                const uint32_t cand = s * (j / s) + q;
+                if ((cand + Q.cbps - 16u * cand / Q.cbps) % s == j % s) i = cand;
+            }
+            const uint32_t k = 16u * (i % col) + i / col;                // i = (cbps/16)*(k%16) + k/16
+            const uint32_t p = sym * Q.cbps + k;                         // punctured index in the frame
+            const uint32_t c = (p / Q.np) * Q.nc + p % Q.np;             // raw_conv.cc:150-159
+            const int bit = (int)raw_coded_bit(frame, Q.frame_bytes, c) * 2 - 1;
+            pt = bit * flip + pt * 2;
+            flip *= -bit;
+        }
+        lv[a] = (float)pt * Q.scale;
+    }
+    out[o] = make_float2(lv[0], lv[1]);
+}
+
 }  // namespace
 
 struct ofdmtx_raw_plan {
@@ -465,6 +529,51 @@ int ofdmtx_raw_modulate(ofdmtx_ctx *ctx, const ofdmtx_raw_plan *pl, const float 
     HIPCHK(hipSetDevice(ctx->device));
     return launch_raw_n(ctx, pl->rp, reinterpret_cast<const float2 *>(d_data), reinterpret_cast<float2 *>(d_mapped),
                         reinterpret_cast<float2 *>(d_iq), (hipStream_t)stream);
+}
+
+int ofdmtx_raw_framebytes(int qambits, int nc, int np, uint64_t size, uint32_t *out)
+{
+    // rawofdm/src/python/raw_qam.py:30-37 (np doubled for the rate-1/2 code), minus the padding byte
+    if (!out || nc <= 0 || np <= 0 || np > nc) return OFDMTX_EINVAL;
+    if (qambits != 1 && qambits != 2 && qambits != 4 && qambits != 6) return OFDMTX_ESHAPE;
+    const uint64_t num = size * (uint64_t)qambits * (uint64_t)nc, den = (uint64_t)np * 2u * 8u;
+    if (num % den != 0 || num / den < 1 || num / den > 0xFFFFFFFFull) return OFDMTX_ESHAPE;
+    *out = (uint32_t)(num / den) - 1u;
+    return OFDMTX_OK;
+}
+
+int ofdmtx_raw_qam_tx(ofdmtx_ctx *ctx, int qambits, int nc, int np, uint32_t ncarriers, uint32_t nsymbols,
+                      const uint8_t *d_bytes, uint64_t n_frames, float *d_out, void *stream)
+{
+    if (!ctx || !d_out || (n_frames && !d_bytes)) return OFDMTX_EINVAL;
+    uint32_t fb;
+    int rc = ofdmtx_raw_framebytes(qambits, nc, np, (uint64_t)ncarriers * nsymbols, &fb);
+    if (rc) return rc;
+    QamTxParams Q;
+    Q.frame_bytes = fb;
+    Q.ncarriers = ncarriers;
+    Q.nsymbols = nsymbols;
+    Q.qambits = (uint32_t)qambits;
+    Q.nc = (uint32_t)nc;
+    Q.np = (uint32_t)np;
+    Q.cbps = (uint32_t)qambits * ncarriers;
+    // the interleaver is a permutation only for whole columns (raw_intrlv.cc:26: cbps / 16) and whole groups of s
+    const uint32_t s = qambits / 2 > 1 ? (uint32_t)qambits / 2 : 1u;
+    if (Q.cbps % 16u != 0 || (Q.cbps / 16u) % s != 0) return OFDMTX_ESHAPE;
+    Q.n_values = n_frames * (uint64_t)ncarriers * nsymbols;
+    if (Q.n_values == 0) return OFDMTX_OK;
+    if ((Q.n_values + 255) / 256 > 0x7FFFFFFFull) return OFDMTX_ETOOBIG;
+    // raw_qam.cc:39-52,120-147: bits per axis and symbol power per constellation, float arithmetic as there
+    const int numbits = qambits == 1 ? 1 : qambits / 2;
+    const float power = qambits == 1 ? 1.0f : 0.5f;
+    const int nn = 1 << (numbits - 1);
+    const int sum2 = (4 * nn * nn * nn - nn) / 3;
+    Q.scale = (float)sqrt(power * float(nn) / float(sum2));
+    HIPCHK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_raw_qam_tx, dim3((unsigned)((Q.n_values + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Q,
+                       d_bytes, reinterpret_cast<float2 *>(d_out));
+    HIPCHK(hipGetLastError());
+    return OFDMTX_OK;
 }
 
 }  // extern "C"

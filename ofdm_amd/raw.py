@@ -214,3 +214,60 @@ class ofdm_mod(object):
         return self._finish(plan, data)
 
     add_options = staticmethod(ofdm_params.add_options)
+
+
+# rawofdm/src/python/raw_qam.py:19-28: bitrate -> (bits per carrier, (nc, np))
+bitrates = {
+    1: (1, (4, 4)),
+    2: (1, (6, 4)),   # marked "DONT USE" in the reference
+    3: (2, (4, 4)),
+    4: (2, (6, 4)),
+    5: (4, (4, 4)),
+    6: (4, (6, 4)),
+    7: (6, (4, 3)),
+    8: (6, (6, 4)),
+}
+
+
+def framebytes(bitrate, size):
+    """rawofdm/src/python/raw_qam.py:30-37: bytes per frame of `size` complex values, padding
+    byte included (the reference asserts divisibility; so does this)."""
+    (qambits, (nc, np_)) = bitrate
+    out = C.c_uint32()
+    rc = _lib.load().ofdmtx_raw_framebytes(int(qambits), int(nc), int(np_), int(size), C.byref(out))
+    if rc == _lib.ESHAPE:
+        raise AssertionError("frame size does not give a whole number of bytes")
+    _lib.check(rc)
+    return out.value + 1
+
+
+class qam_tx(object):
+    """rawofdm/src/python/raw_qam.py:76-112: whole frames of `framebytes` bytes in, nsymbols *
+    ncarriers complex values per frame out (pad -> conv_enc -> conv_punc -> intrlv_bit -> qam_enc),
+    as one HIP kernel."""
+
+    def __init__(self, bitrate, ncarriers, nsymbols, log=False, ctx=None, device=0):
+        (self.qambits, (self.nc, self.np)) = bitrates[bitrate]
+        self.ncarriers, self.nsymbols = int(ncarriers), int(nsymbols)
+        self.framebytes = framebytes((self.qambits, (self.nc, self.np)), self.ncarriers * self.nsymbols)
+        self.framebytes -= 1                                     # room for padding (raw_qam.py:83)
+        self.ctx = ctx if ctx is not None else TxContext(device)
+        if log:
+            raise NotImplementedError("the per-block taps of qam_tx are not materialised (one fused kernel)")
+
+    def modulate(self, data, out=None):
+        """data: uint8 tensor / bytes holding whole frames.  Returns a complex64 tensor."""
+        dev = self.ctx.device
+        if not torch.is_tensor(data):
+            data = torch.frombuffer(bytearray(bytes(data)) or bytearray(1), dtype=torch.uint8)
+        data = data.to(dev).contiguous().reshape(-1)
+        if data.dtype != torch.uint8 or data.numel() % self.framebytes:
+            raise ValueError("data must be uint8 and hold whole frames of %d bytes" % self.framebytes)
+        n_frames = data.numel() // self.framebytes
+        n_out = n_frames * self.nsymbols * self.ncarriers
+        vals = out if out is not None else torch.empty(n_out, dtype=torch.complex64, device=dev)
+        if vals.numel() < n_out or vals.dtype != torch.complex64:
+            raise ValueError("output must be complex64 with >= %d values" % n_out)
+        _lib.check(self.ctx._lib.ofdmtx_raw_qam_tx(self.ctx._h, self.qambits, self.nc, self.np, self.ncarriers,
+                                                   self.nsymbols, _ptr(data), n_frames, _ptr(vals), _stream(dev)))
+        return vals

@@ -209,3 +209,110 @@ def test_gpu_loopback_large(txctx, n, cp):
     # average transmit power per sample ~ occupied fraction of the band
     pw = np.mean(np.abs(rows[:, 3:]) ** 2)
     assert abs(pw - (p.occupied_tones - 1) / n) < 0.01
+
+
+# ------------------------------------------------------------------------------ TX bit chain, CPU
+
+@pytest.mark.parametrize("nbits", [1, 2, 4, 6])
+def test_oracle_intrlv_roundtrip(nbits):
+    """rawofdm/src/python/qa_intrlv.py:19-40."""
+    rng = np.random.default_rng(nbits)
+    data = rng.integers(0, 2, 10 * 48 * nbits).astype(np.uint8)
+    enc = ro.intrlv_bit(data, 48, nbits, False)
+    assert np.array_equal(ro.intrlv_bit(enc, 48, nbits, True), data)
+    assert sorted(ro.intrlv_bit_map(48, nbits)) == list(range(48 * nbits))
+
+
+@pytest.mark.parametrize("nbits", [1, 2, 4, 6])
+def test_oracle_qam_roundtrip_and_power(nbits):
+    """rawofdm/src/python/qa_qam.py:16-52: slicing the decoder's confidences at 128 returns the
+    bits; average symbol power is 1."""
+    rng = np.random.default_rng(10 + nbits)
+    bits = rng.integers(0, 2, 6000 * nbits).astype(np.uint8)
+    sym = ro.qam_enc(bits, nbits)
+    dec = ro.qam_dec(sym, nbits)
+    assert np.array_equal((dec.astype(int) - 128 >= 0).astype(np.uint8), bits)
+    allbits = np.array([[(v >> (nbits - 1 - i)) & 1 for i in range(nbits)] for v in range(1 << nbits)]).reshape(-1)
+    assert abs(np.mean(np.abs(ro.qam_enc(allbits, nbits)) ** 2) - 1.0) < 1e-6
+
+
+@pytest.mark.parametrize("nc,np_", [(4, 4), (6, 4), (4, 3)])
+def test_oracle_conv_roundtrip(nc, np_):
+    """rawofdm/src/python/qa_conv.py:37-105 at a smaller length: puncture, de-puncture with
+    erasures, decode = identity (last byte is the zero padding)."""
+    rng = np.random.default_rng(nc * 10 + np_)
+    data = bytearray(rng.integers(0, 256, 96, dtype=np.uint8).tobytes())
+    data[-1] = 0
+    coded, _ = ro.conv_enc(data)
+    punct = ro.conv_punc(coded, nc, np_)
+    assert len(punct) == len(data) * 8 * 2 * np_ // nc
+    soft = ro.conv_punc(punct * 255, np_, nc, 128)
+    assert ro.viterbi_decode(soft, len(data) * 8) == bytes(data)
+
+
+@pytest.mark.parametrize("bitrate", range(1, 9))
+def test_oracle_fullstack_noiseless(bitrate):
+    """rawofdm/src/python/qa_qamconv.py:36-133 without the noise source: 14 symbols x 48
+    carriers per frame, several frames, received bytes = sent bytes."""
+    rng = np.random.default_rng(bitrate)
+    qambits, punc = ro.BITRATES[bitrate]
+    fb = ro.framebytes((qambits, punc), 48 * 16) - 1
+    data = rng.integers(0, 256, 3 * fb, dtype=np.uint8).tobytes()
+    values, taps = ro.qam_tx(bitrate, 48, 16, data)
+    assert len(values) == 3 * 48 * 16
+    assert ro.qam_rx(bitrate, 48, 16, values) == data
+
+
+# ------------------------------------------------------------------------------ TX bit chain, GPU
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bitrate", range(1, 9))
+@pytest.mark.parametrize("ncarriers,nsymbols", [(48, 16), (192, 16), (768, 4)])
+def test_gpu_qam_tx_bit_exact(txctx, bitrate, ncarriers, nsymbols):
+    import torch
+    from ofdm_amd import raw
+    rng = np.random.default_rng(100 * bitrate + ncarriers)
+    tx = raw.qam_tx(bitrate, ncarriers, nsymbols, ctx=txctx)
+    qambits, punc = ro.BITRATES[bitrate]
+    assert tx.framebytes == ro.framebytes((qambits, punc), ncarriers * nsymbols) - 1
+    data = rng.integers(0, 256, 7 * tx.framebytes, dtype=np.uint8)
+    got = tx.modulate(torch.from_numpy(data)).cpu().numpy()
+    want, _ = ro.qam_tx(bitrate, ncarriers, nsymbols, data.tobytes())
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bitrate,nfft", [(1, 64), (4, 256), (6, 256), (7, 1024), (8, 1024)])
+def test_gpu_bytes_to_iq_and_back(txctx, bitrate, nfft):
+    """Bytes -> qam_tx -> ofdm_mod on the GPU; an ideal receiver (FFT, de-map, soft decisions,
+    de-interleave, de-puncture, maximum-likelihood decoder) returns the bytes: the noiseless case of
+    rawofdm/src/python/qa_qamconv.py joined with qa_ofdm.py."""
+    from ofdm_amd import raw
+    rng = np.random.default_rng(bitrate)
+    opt = ro.Options(fft_length=nfft, occupied_tones=int(0.8125 * nfft), cp_length=nfft // 4)
+    p = ro.OfdmParams(opt)
+    nsymbols, n_frames = 16, 3
+    tx = raw.qam_tx(bitrate, p.data_tones, nsymbols, ctx=txctx)
+    data = rng.integers(0, 256, n_frames * tx.framebytes, dtype=np.uint8).tobytes()
+    values = tx.modulate(data)
+    iq = raw.ofdm_mod(opt, ctx=txctx).modulate_frames(values, nsymbols).cpu().numpy()
+    rows = iq.reshape(n_frames, 3 + nsymbols, -1)[:, 3:].reshape(n_frames * nsymbols, -1)
+    rx = ideal_demod(p, rows).reshape(-1).astype(np.complex64)
+    assert ro.qam_rx(bitrate, p.data_tones, nsymbols, rx) == data
+
+
+@pytest.mark.gpu
+def test_gpu_qam_tx_rejects_bad_geometry(txctx):
+    from ofdm_amd import _lib, raw
+    with pytest.raises(AssertionError):            # raw_qam.py:35
+        raw.qam_tx(8, 50, 3, ctx=txctx)
+    tx = raw.qam_tx(8, 48, 16, ctx=txctx)
+    with pytest.raises(ValueError):
+        tx.modulate(b"\x00" * (tx.framebytes + 1))
+    tx.ncarriers, tx.nsymbols = 40, 16             # 6 * 40 = 240 bits per symbol: a multiple of 16, but ...
+    tx.framebytes = raw.framebytes((6, (6, 4)), 40 * 16) - 1
+    tx.modulate(b"\x00" * tx.framebytes)           # ... 15 columns of 3: still a permutation, accepted
+    tx.ncarriers = 44                              # 264 bits: 16.5 columns -> not a permutation
+    tx.framebytes = raw.framebytes((6, (6, 4)), 44 * 16) - 1
+    with pytest.raises(_lib.OfdmTxError):
+        tx.modulate(b"\x00" * tx.framebytes)
