@@ -283,38 +283,106 @@ __device__ __forceinline__ uint32_t raw_coded_bit(const uint8_t *frame, uint32_t
     return __popc(reg & ((c & 1u) ? 91u : 121u)) & 1u;
 }
 
-__global__ void __launch_bounds__(256) k_raw_qam_tx(QamTxParams Q, const uint8_t *__restrict__ data,
-                                                    float2 *__restrict__ out)
+// One workgroup walks rows (one OFDM symbol of one frame each) with a grid stride; its threads take
+// the row's carriers.  Per row the encoder runs word-parallel first: every thread turns 32 input
+// bits into 64 coded bits (both polynomials as XORs of shifted windows, interleaved A0 B0 A1 B1 ..)
+// in LDS; the carriers then pick their bits from there.  The inverse interleaver map of a symbol
+// (interleaved position -> punctured index) is computed once per workgroup into LDS.  QB / NC / NP
+// are the table entries of rawofdm/src/python/raw_qam.py:19-28 as compile-time constants (NC = 0:
+// taken from Q at run time).
+__device__ __forceinline__ uint64_t spread_bits(uint32_t v)      // bit i -> bit 2i
 {
-    const uint64_t o = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    if (o >= Q.n_values) return;
-    const uint32_t per_frame = Q.ncarriers * Q.nsymbols;
-    const uint64_t f = o / per_frame;
-    const uint32_t r = (uint32_t)(o - f * per_frame), sym = r / Q.ncarriers, car = r - sym * Q.ncarriers;
-    const uint8_t *frame = data + f * Q.frame_bytes;
-    const uint32_t s = Q.qambits / 2u > 1u ? Q.qambits / 2u : 1u, col = Q.cbps / 16u;
-    const uint32_t axis_bits = Q.qambits == 1u ? 1u : Q.qambits / 2u;
-    float lv[2] = {0.f, 0.f};
-    for (uint32_t a = 0; a * axis_bits < Q.qambits; a++) {
-        int pt = 0, flip = 1;                                // rawofdm/src/lib/qam/raw_qam.cc:63-74
-        for (uint32_t t = 0; t < axis_bits; t++) {
-            const uint32_t j = car * Q.qambits + a * axis_bits + t;     // position in the interleaved symbol
-            // invert rawofdm/src/lib/qam/raw_intrlv.cc:22-30: j = s*(i/s) + (i + cbps - 16*i/cbps) % s
-            uint32_t i = 0;
-            for (uint32_t q = 0; q < s; q++) {
-                const uint32_t cand = s * (j / s) + q;
-                if ((cand + Q.cbps - 16u * cand / Q.cbps) % s == j % s) i = cand;
-            }
-            const uint32_t k = 16u * (i % col) + i / col;                // i = (cbps/16)*(k%16) + k/16
-            const uint32_t p = sym * Q.cbps + k;                         // punctured index in the frame
-            const uint32_t c = (p / Q.np) * Q.nc + p % Q.np;             // raw_conv.cc:150-159
-            const int bit = (int)raw_coded_bit(frame, Q.frame_bytes, c) * 2 - 1;
-            pt = bit * flip + pt * 2;
-            flip *= -bit;
-        }
-        lv[a] = (float)pt * Q.scale;
+    uint64_t x = v;
+    x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+    x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x << 2)) & 0x3333333333333333ull;
+    x = (x | (x << 1)) & 0x5555555555555555ull;
+    return x;
+}
+
+// 32 bits of the padded frame starting at bit position `pos` (may be negative), MSB first
+__device__ __forceinline__ uint32_t frame_bits32(const uint8_t *frame, uint32_t frame_bytes, int64_t pos)
+{
+    uint64_t acc = 0;
+    const int64_t b0 = pos >> 3;                                  // floor for negatives too
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        const int64_t b = b0 + i;
+        acc = (acc << 8) | ((b >= 0 && (uint64_t)b < frame_bytes) ? frame[b] : 0u);
     }
-    out[o] = make_float2(lv[0], lv[1]);
+    return (uint32_t)(acc >> (8u - (uint32_t)(pos & 7)));
+}
+
+template <int QB, int NC, int NP>
+__global__ void __launch_bounds__(256) k_raw_qam_tx(QamTxParams Q, const uint8_t *__restrict__ data,
+                                                    float2 *__restrict__ out, uint32_t cod_words, uint32_t rows_per_iter)
+{
+    extern __shared__ uint32_t s_qam[];
+    uint32_t *s_cod = s_qam;                                      // coded bits of the row, MSB first
+    uint16_t *s_k = reinterpret_cast<uint16_t *>(s_qam + cod_words * rows_per_iter);
+    const uint32_t qambits = QB ? (uint32_t)QB : Q.qambits;
+    const uint32_t nc = NC ? (uint32_t)NC : Q.nc, np = NC ? (uint32_t)NP : Q.np;
+    const uint32_t s = qambits / 2u > 1u ? qambits / 2u : 1u, col = Q.cbps / 16u;
+    for (uint32_t j = threadIdx.x; j < Q.cbps; j += blockDim.x) {
+        // invert rawofdm/src/lib/qam/raw_intrlv.cc:22-30: j = s*(i/s) + (i + cbps - 16*i/cbps) % s,
+        // i = (cbps/16)*(k%16) + k/16
+        uint32_t i = 0;
+        for (uint32_t q = 0; q < s; q++) {
+            const uint32_t cand = s * (j / s) + q;
+            if ((cand + Q.cbps - 16u * cand / Q.cbps) % s == j % s) i = cand;
+        }
+        s_k[j] = (uint16_t)(16u * (i % col) + i / col);
+    }
+
+    const uint32_t axis_bits = qambits == 1u ? 1u : qambits / 2u;
+    const uint64_t n_rows = Q.n_values / Q.ncarriers;
+    const uint32_t cod_per_row = Q.cbps / np * nc;                // coded bits behind one symbol
+    const uint32_t words_per_row = (cod_per_row + 63u) / 64u;     // 32-bit input words feeding one symbol
+    // rows_per_iter consecutive rows per pass, so that short symbols still fill the workgroup
+    for (uint64_t row0 = (uint64_t)blockIdx.x * rows_per_iter; row0 < n_rows; row0 += (uint64_t)gridDim.x * rows_per_iter) {
+        const uint32_t rows_here = n_rows - row0 < rows_per_iter ? (uint32_t)(n_rows - row0) : rows_per_iter;
+        __syncthreads();                                          // previous rows consumed (and s_k written)
+        // ---- rawofdm/src/lib/qam/raw_conv.cc:46-51 for the input bits behind each symbol:
+        // polynomial 121 taps u[n], u[n-3..n-6]; 91 taps u[n], u[n-1], u[n-3], u[n-4], u[n-6]
+        for (uint32_t idx = threadIdx.x; idx < rows_here * words_per_row; idx += blockDim.x) {
+            const uint32_t r = idx / words_per_row, w = idx - r * words_per_row;
+            const uint64_t row = row0 + r, f = row / Q.nsymbols;
+            const uint32_t sym = (uint32_t)(row - f * Q.nsymbols);
+            const uint8_t *frame = data + f * Q.frame_bytes;
+            const int64_t n0 = (int64_t)((sym * cod_per_row) >> 1) + 32 * (int64_t)w;
+            const uint32_t prev = frame_bits32(frame, Q.frame_bytes, n0 - 32), cur = frame_bits32(frame, Q.frame_bytes, n0);
+            const uint32_t y1 = __funnelshift_r(cur, prev, 1), y3 = __funnelshift_r(cur, prev, 3);
+            const uint32_t y4 = __funnelshift_r(cur, prev, 4), y5 = __funnelshift_r(cur, prev, 5);
+            const uint32_t y6 = __funnelshift_r(cur, prev, 6);
+            const uint32_t aw = cur ^ y3 ^ y4 ^ y5 ^ y6, bw = cur ^ y1 ^ y3 ^ y4 ^ y6;
+            const uint64_t both = (spread_bits(aw) << 1) | spread_bits(bw);     // A before B, MSB first
+            s_cod[r * cod_words + 2u * w] = (uint32_t)(both >> 32);
+            s_cod[r * cod_words + 2u * w + 1u] = (uint32_t)both;
+        }
+        __syncthreads();
+        for (uint32_t idx = threadIdx.x; idx < rows_here * Q.ncarriers; idx += blockDim.x) {
+            const uint32_t r = idx / Q.ncarriers, car = idx - r * Q.ncarriers;
+            const uint32_t *cod = s_cod + r * cod_words;
+            float lv[2] = {0.f, 0.f};
+#pragma unroll
+            for (uint32_t a = 0; a < 2u; a++) {
+                if (a * axis_bits >= qambits) break;
+                int pt = 0, flip = 1;                             // rawofdm/src/lib/qam/raw_qam.cc:63-74
+#pragma unroll
+                for (uint32_t t = 0; t < 3u; t++) {
+                    if (t >= axis_bits) break;
+                    const uint32_t k = s_k[car * qambits + a * axis_bits + t];
+                    const uint32_t c = (k / np) * nc + k % np;    // raw_conv.cc:150-159, relative to the symbol
+                    const int bit = (int)((cod[c >> 5] >> (31u - (c & 31u))) & 1u) * 2 - 1;
+                    pt = bit * flip + pt * 2;
+                    flip *= -bit;
+                }
+                lv[a] = (float)pt * Q.scale;
+            }
+            out[(row0 + r) * Q.ncarriers + car] = make_float2(lv[0], lv[1]);
+        }
+    }
 }
 
 }  // namespace
@@ -562,7 +630,6 @@ int ofdmtx_raw_qam_tx(ofdmtx_ctx *ctx, int qambits, int nc, int np, uint32_t nca
     if (Q.cbps % 16u != 0 || (Q.cbps / 16u) % s != 0) return OFDMTX_ESHAPE;
     Q.n_values = n_frames * (uint64_t)ncarriers * nsymbols;
     if (Q.n_values == 0) return OFDMTX_OK;
-    if ((Q.n_values + 255) / 256 > 0x7FFFFFFFull) return OFDMTX_ETOOBIG;
     // raw_qam.cc:39-52,120-147: bits per axis and symbol power per constellation, float arithmetic as there
     const int numbits = qambits == 1 ? 1 : qambits / 2;
     const float power = qambits == 1 ? 1.0f : 0.5f;
@@ -570,8 +637,34 @@ int ofdmtx_raw_qam_tx(ofdmtx_ctx *ctx, int qambits, int nc, int np, uint32_t nca
     const int sum2 = (4 * nn * nn * nn - nn) / 3;
     Q.scale = (float)sqrt(power * float(nn) / float(sum2));
     HIPCHK(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(k_raw_qam_tx, dim3((unsigned)((Q.n_values + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Q,
-                       d_bytes, reinterpret_cast<float2 *>(d_out));
+    const uint64_t n_rows = n_frames * (uint64_t)nsymbols;
+    const uint64_t cap = (uint64_t)ctx->n_cu * 8u;
+    // a symbol must start on a whole puncturing group (true for every table entry of raw_qam.py:19-28)
+    if (Q.cbps % (uint32_t)np != 0) return OFDMTX_ESHAPE;
+    const uint32_t cod_words = ((Q.cbps / (uint32_t)np * (uint32_t)nc + 63u) / 64u) * 2u;
+    const uint32_t rows_per_iter = ncarriers >= 1024u ? 1u : 1024u / ncarriers;
+    const size_t lds = (size_t)cod_words * rows_per_iter * sizeof(uint32_t) + (size_t)Q.cbps * sizeof(uint16_t);
+    if (lds > 60000) return OFDMTX_ESHAPE;
+    const unsigned threads = 256u;
+    const uint64_t n_iters = (n_rows + rows_per_iter - 1) / rows_per_iter;
+    const unsigned grid = (unsigned)(n_iters < cap ? n_iters : cap);
+    hipStream_t st = (hipStream_t)stream;
+    float2 *o2 = reinterpret_cast<float2 *>(d_out);
+#define LAUNCH_QAM(QB_, NC_, NP_) \
+    hipLaunchKernelGGL((k_raw_qam_tx<QB_, NC_, NP_>), dim3(grid), dim3(threads), lds, st, Q, d_bytes, o2, cod_words, rows_per_iter)
+    const int key = qambits * 100 + nc * 10 + np;
+    switch (key) {
+    case 144: LAUNCH_QAM(1, 4, 4); break;
+    case 164: LAUNCH_QAM(1, 6, 4); break;
+    case 244: LAUNCH_QAM(2, 4, 4); break;
+    case 264: LAUNCH_QAM(2, 6, 4); break;
+    case 444: LAUNCH_QAM(4, 4, 4); break;
+    case 464: LAUNCH_QAM(4, 6, 4); break;
+    case 643: LAUNCH_QAM(6, 4, 3); break;
+    case 664: LAUNCH_QAM(6, 6, 4); break;
+    default: LAUNCH_QAM(0, 0, 0); break;
+    }
+#undef LAUNCH_QAM
     HIPCHK(hipGetLastError());
     return OFDMTX_OK;
 }

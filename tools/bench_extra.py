@@ -100,6 +100,20 @@ def main():
              % (nfft, cp, n_frames * 16), ms, data.numel() * 8 + plan.n_samples * 8, plan.n_samples,
              {"data_symbols": n_frames * 16})
         del iq, data, plan
+    bench_qam_tx(ctx, a.steps)
+
+
+def bench_qam_tx(ctx, steps):
+    """bytes -> carrier values (the bit chain in front of the variable-size modulator)"""
+    dev = ctx.device
+    for bitrate, ncar in ((8, 192), (8, 768), (5, 192), (1, 192)):
+        tx = raw.qam_tx(bitrate, ncar, 16, ctx=ctx)
+        n_frames = (1 << 20) // 16 if ncar == 192 else (1 << 18) // 16
+        data = torch.randint(0, 256, (n_frames * tx.framebytes,), dtype=torch.uint8, device=dev)
+        out = torch.empty(n_frames * 16 * ncar, dtype=torch.complex64, device=dev)
+        ms = timed(lambda: tx.modulate(data, out=out), steps)
+        line("rawofdm qam_tx bitrate %d, %d carriers x 16 symbols per frame, %d frames" % (bitrate, ncar, n_frames),
+             ms, data.numel() + out.numel() * 8, out.numel(), {"frames": n_frames})
 
 
 if __name__ == "__main__":
