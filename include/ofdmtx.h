@@ -7,6 +7,9 @@
  * crosses this boundary.  A context is bound to one device and is thread-compatible (use
  * one per device / per host thread).  Kernels are enqueued on the stream passed in
  * (a hipStream_t passed as void*; NULL = the default stream) and are NOT synchronised.
+ * Payload bytes are fetched as aligned 32-bit words: the kernels may read up to 3 bytes on either
+ * side of a payload (never written, never used) -- keep payload buffers inside one allocation.
+ * With an empty plan (0 packets / symbols) the kernel entry points return 0 and touch no buffer.
  *
  * What each entry point stands in for in the reference (paths relative to the reference
  * root, ftw_80211_ofdm_tx/src/...):

@@ -591,9 +591,9 @@ int ofdmtx_raw_plan_get_sizes(const ofdmtx_raw_plan *pl, ofdmtx_raw_sizes *out)
 int ofdmtx_raw_modulate(ofdmtx_ctx *ctx, const ofdmtx_raw_plan *pl, const float *d_data, float *d_mapped,
                         float *d_iq, void *stream)
 {
-    if (!ctx || !pl || pl->ctx != ctx || !d_iq) return OFDMTX_EINVAL;
-    if (!d_data && pl->rp.n_sym) return OFDMTX_EINVAL;
+    if (!ctx || !pl || pl->ctx != ctx) return OFDMTX_EINVAL;
     if (pl->rp.n_sym == 0) return OFDMTX_OK;
+    if (!d_iq || !d_data) return OFDMTX_EINVAL;
     HIPCHK(hipSetDevice(ctx->device));
     return launch_raw_n(ctx, pl->rp, reinterpret_cast<const float2 *>(d_data), reinterpret_cast<float2 *>(d_mapped),
                         reinterpret_cast<float2 *>(d_iq), (hipStream_t)stream);
@@ -613,7 +613,7 @@ int ofdmtx_raw_framebytes(int qambits, int nc, int np, uint64_t size, uint32_t *
 int ofdmtx_raw_qam_tx(ofdmtx_ctx *ctx, int qambits, int nc, int np, uint32_t ncarriers, uint32_t nsymbols,
                       const uint8_t *d_bytes, uint64_t n_frames, float *d_out, void *stream)
 {
-    if (!ctx || !d_out || (n_frames && !d_bytes)) return OFDMTX_EINVAL;
+    if (!ctx || (n_frames && (!d_bytes || !d_out))) return OFDMTX_EINVAL;
     uint32_t fb;
     int rc = ofdmtx_raw_framebytes(qambits, nc, np, (uint64_t)ncarriers * nsymbols, &fb);
     if (rc) return rc;

@@ -1414,9 +1414,10 @@ int ofdmtx_encode_bits(ofdmtx_ctx *ctx, const ofdmtx_plan *pl, const uint8_t *d_
                        uint8_t *d_plcp, uint8_t *d_scrambled, uint8_t *d_coded,
                        uint8_t *d_interleaved, void *stream)
 {
-    if (!ctx || !pl || pl->ctx != ctx || !d_interleaved) return OFDMTX_EINVAL;
+    if (!ctx || !pl || pl->ctx != ctx) return OFDMTX_EINVAL;
+    if (pl->pp.n_pkts == 0) return OFDMTX_OK;              // nothing to do: buffers may be NULL
+    if (!d_interleaved) return OFDMTX_EINVAL;
     if (!d_payloads && pl->sizes.payload_bytes) return OFDMTX_EINVAL;
-    if (pl->pp.n_pkts == 0) return OFDMTX_OK;
     HIPCHK(hipSetDevice(ctx->device));
     const int grid = grid_for(ctx, pl->pp.n_pkts, ENC_WAVES, 8);
     hipStream_t st = (hipStream_t)stream;
@@ -1501,8 +1502,9 @@ extern "C" {
 int ofdmtx_modulate(ofdmtx_ctx *ctx, const ofdmtx_plan *pl, const uint8_t *d_msg, float *d_mapped,
                     float *d_iq, void *stream)
 {
-    if (!ctx || !pl || pl->ctx != ctx || !d_msg || !d_iq) return OFDMTX_EINVAL;
+    if (!ctx || !pl || pl->ctx != ctx) return OFDMTX_EINVAL;
     if (pl->pp.n_pkts == 0) return OFDMTX_OK;
+    if (!d_msg || !d_iq) return OFDMTX_EINVAL;
     HIPCHK(hipSetDevice(ctx->device));
     return launch_tx<true>(ctx, pl, d_msg, reinterpret_cast<float2 *>(d_mapped), reinterpret_cast<float2 *>(d_iq),
                            (hipStream_t)stream);
@@ -1512,9 +1514,10 @@ int ofdmtx_tx(ofdmtx_ctx *ctx, const ofdmtx_plan *pl, const uint8_t *d_payloads,
               float *d_iq, void *stream)
 {
     (void)d_work;   // the fused kernel keeps the mapper messages in LDS
-    if (!ctx || !pl || pl->ctx != ctx || !d_iq) return OFDMTX_EINVAL;
-    if (!d_payloads && pl->sizes.payload_bytes) return OFDMTX_EINVAL;
+    if (!ctx || !pl || pl->ctx != ctx) return OFDMTX_EINVAL;
     if (pl->pp.n_pkts == 0) return OFDMTX_OK;
+    if (!d_iq) return OFDMTX_EINVAL;
+    if (!d_payloads && pl->sizes.payload_bytes) return OFDMTX_EINVAL;
     HIPCHK(hipSetDevice(ctx->device));
     return launch_tx<false>(ctx, pl, d_payloads, nullptr, reinterpret_cast<float2 *>(d_iq), (hipStream_t)stream);
 }

@@ -140,3 +140,90 @@ def test_symbol_chunk_boundaries(txctx, c_oracle, regime, n_sym):
     pay = rng.integers(0, 256, sum(lens), dtype=np.uint8)
     plan = txctx.plan_ragged(regs, lens, pilot_start=100, flags=flags, amp=0.3)
     check_plan(plan, pay, lens, regs, c_oracle, flags, 0.3)
+
+
+def test_empty_plans(txctx):
+    plan = txctx.plan_uniform(0, 8, 100)
+    assert plan.n_samples == 0 and plan.n_pkts == 0
+    empty = torch.empty(0, dtype=torch.uint8, device=txctx.device)
+    assert plan.tx(empty).numel() == 0
+    plan = txctx.plan_ragged(np.zeros(0, np.uint8), np.zeros(0, np.uint32))
+    assert plan.n_samples == 0
+    assert plan.modulate(plan.encode_bits(empty)).numel() == 0
+
+
+def test_payload_stride_and_offsets(txctx, c_oracle):
+    """Payloads need not be packed: a stride for uniform batches, arbitrary (also odd) byte offsets
+    for ragged ones."""
+    rng = np.random.default_rng(21)
+    n, ln, stride = 6, 333, 401                       # odd stride: every other payload is misaligned
+    buf = rng.integers(0, 256, n * stride, dtype=np.uint8)
+    dev = txctx.device
+    flags = _lib.F_PREAMBLE | _lib.F_ZEROGAP
+    plan = txctx.plan_uniform(n, 4, ln, payload_stride=stride)
+    iq = plan.tx(torch.from_numpy(buf).to(dev)).cpu().numpy()
+    lay = plan.layout()
+    for i in range(n):
+        ref = c_oracle.encode_bits(buf[i * stride:i * stride + ln].tobytes(), 4)
+        want = c_oracle.modulate(ref["interleaved"], 4, int(lay["pilot_base"][i]), 0.3, flags)["iq64"]
+        a = int(lay["sample_off"][i])
+        assert rel_l2_rows(iq[a:a + len(want)], want).max() <= REL_L2_TOL
+    lens = np.array([10, 77, 1500, 3], np.uint32)
+    offs = np.array([1, 131, 255, 2001], np.uint64)
+    regs = np.array([1, 6, 8, 3], np.uint8)
+    plan = txctx.plan_ragged(regs, lens, payload_off=offs)
+    assert plan.payload_bytes == 2004
+    iq = plan.tx(torch.from_numpy(buf).to(dev)).cpu().numpy()
+    lay = plan.layout()
+    for i in range(4):
+        ref = c_oracle.encode_bits(buf[int(offs[i]):int(offs[i]) + int(lens[i])].tobytes(), int(regs[i]))
+        want = c_oracle.modulate(ref["interleaved"], int(regs[i]), int(lay["pilot_base"][i]), 0.3, flags)["iq64"]
+        a = int(lay["sample_off"][i])
+        assert rel_l2_rows(iq[a:a + len(want)], want).max() <= REL_L2_TOL
+
+
+def test_side_stream(txctx):
+    """Kernels go to the caller's stream: a side stream gives the same bits as the default one."""
+    rng = np.random.default_rng(22)
+    n, ln = 2000, 700
+    payloads = torch.from_numpy(rng.integers(0, 256, n * ln, dtype=np.uint8)).to(txctx.device)
+    plan = txctx.plan_uniform(n, 7, ln)
+    ref = plan.tx(payloads)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(device=txctx.device)
+    with torch.cuda.stream(side):
+        got = plan.tx(payloads)
+        got2 = plan.modulate(plan.encode_bits(payloads))
+    side.synchronize()
+    assert torch.equal(got.view(torch.float32), ref.view(torch.float32))
+    assert torch.equal(got2.view(torch.float32), ref.view(torch.float32))
+
+
+def test_custom_constellation(txctx, c_oracle):
+    """The `constellation` argument of ftw.ofdm_mapper (ftw/ftw.i:157-163): replaced points show up
+    in the mapper tap and in the IQ; the SIGNAL symbol keeps its fixed BPSK."""
+    from ofdm_amd.batch import TxContext
+    ctx = TxContext(0)                                 # own context: the shared one keeps the defaults
+    rng = np.random.default_rng(23)
+    pts = (rng.standard_normal(4) + 1j * rng.standard_normal(4)).astype(np.complex64)
+    ctx.set_constellation(2, pts)
+    n, ln = 3, 50
+    payloads = rng.integers(0, 256, n * ln, dtype=np.uint8)
+    plan = ctx.plan_uniform(n, 3, ln)
+    dev = ctx.device
+    msg = plan.encode_bits(torch.from_numpy(payloads).to(dev))
+    iq, mapped = plan.modulate(msg, want_mapped=True)
+    iq2 = plan.tx(torch.from_numpy(payloads).to(dev))
+    assert torch.equal(iq.view(torch.float32), iq2.view(torch.float32))
+    mapped = mapped.cpu().numpy()
+    lay = plan.layout()
+    for i in range(n):
+        ref = c_oracle.encode_bits(payloads[i * ln:(i + 1) * ln].tobytes(), 3)
+        bits = np.unpackbits(np.frombuffer(ref["interleaved"], np.uint8))
+        so, ns = int(lay["sym_off"][i]), int(lay["n_sym"][i])
+        assert np.array_equal(mapped[so], (2.0 * bits[:48] - 1).astype(np.complex64))
+        idx = bits[48:48 + ns * 96].reshape(-1, 2) @ np.array([2, 1])
+        assert np.array_equal(mapped[so + 1:so + 1 + ns].reshape(-1), pts[idx])
+    with pytest.raises(_lib.OfdmTxError):
+        ctx.set_constellation(3, pts)
+    ctx.close()
