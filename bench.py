@@ -55,7 +55,16 @@ def cpu_baseline(n_sample, threads):
     t0 = time.perf_counter()
     c_oracle.tx_batch(payloads, **args)
     dt = time.perf_counter() - t0
+    # one thread on a proportionally smaller sample, for the per-core figure
+    n1 = max(64, n_sample // threads)
+    a1 = dict(args, pay_off=args["pay_off"][:n1], pay_len=args["pay_len"][:n1], regimes=args["regimes"][:n1],
+              pilot_off=args["pilot_off"][:n1], msg_off=args["msg_off"][:n1], iq_off=args["iq_off"][:n1],
+              msg_total=n1 * info.msg_len, iq_total=n1 * samples, threads=1)
+    t1 = time.perf_counter()
+    c_oracle.tx_batch(payloads[:n1 * PAYLOAD], **a1)
+    dt1 = time.perf_counter() - t1
     return {"value": n_sample * samples / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
+            "value_one_core": n1 * samples / dt1 / 1e6,
             "sample": "%d packets (54 Mbps, 1500 B) payload->IQ by oracle/ftw_oracle.c, %.1f s wall on %d threads; "
                       "restatement, not GNU Radio" % (n_sample, dt, threads)}
 
@@ -80,6 +89,9 @@ def main():
     ap.add_argument("--fused", type=int, default=1, help="1: single fused kernel (ofdmtx_tx), 0: two kernels")
     ap.add_argument("--stage-steps", type=int, default=3, help="untimed extra passes of the two-kernel path")
     ap.add_argument("--cpu-sample", type=int, default=100_000, help="packets timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--gather", type=int, default=0,
+                    help="1: every step also collects all shards' IQ on rank 0 (RCCL send/recv); size --packets so "
+                         "that N shards fit one GPU")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -122,6 +134,9 @@ def main():
             plan.modulate(msg, out=iq)                   # k_tx, message input
         if events is not None:
             events[2].record()
+        if a.gather and dist:
+            from ofdm_amd.dist import gather_iq
+            gather_iq(iq, dst=0)
 
     for _ in range(a.warmup):
         step()
@@ -183,7 +198,8 @@ def main():
                                    "full PPDU IQ (4 preamble rows + SIGNAL + %d DATA symbols + 13 zero rows)"
                                    % (n, info.n_sym),
                        "packets_per_gpu": n, "samples_per_packet": info.n_rows * 80,
-                       "parallelism": "packets sharded by index over %d GPU(s), no collective" % world},
+                       "parallelism": "packets sharded by index over %d GPU(s), %s" % (
+                           world, "IQ gathered on rank 0 every step" if (a.gather and world > 1) else "no collective")},
             "kernel_ms": kernels,
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
