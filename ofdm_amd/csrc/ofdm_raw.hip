@@ -389,6 +389,7 @@ __global__ void __launch_bounds__(256) k_raw_qam_tx(QamTxParams Q, const uint8_t
 
 struct ofdmtx_raw_plan {
     ofdmtx_ctx *ctx;
+    int device;
     RawParams rp;
     ofdmtx_raw_sizes sizes;
     int16_t *d_src;
@@ -434,6 +435,7 @@ int raw_plan_common(ofdmtx_ctx *ctx, uint32_t n, uint32_t cp, const int32_t *car
     if (!pl) return OFDMTX_ENOMEM;
     memset(pl, 0, sizeof(*pl));
     pl->ctx = ctx;
+    pl->device = ctx->device;
     RawParams &rp = pl->rp;
     rp.n = n;
     rp.cp = cp;
@@ -571,7 +573,7 @@ int ofdmtx_raw_plan_flags(ofdmtx_ctx *ctx, uint32_t fft_length, uint32_t cp_leng
 int ofdmtx_raw_plan_destroy(ofdmtx_raw_plan *pl)
 {
     if (!pl) return OFDMTX_EINVAL;
-    (void)hipSetDevice(pl->ctx->device);
+    (void)hipSetDevice(pl->device);
     if (pl->d_src) (void)hipFree(pl->d_src);
     if (pl->d_tw) (void)hipFree(pl->d_tw);
     if (pl->d_pre_rows) (void)hipFree(pl->d_pre_rows);

@@ -1011,6 +1011,7 @@ DevTables ofdmtx_ctx::tables() const
 
 struct ofdmtx_plan {
     ofdmtx_ctx *ctx;
+    int device;            // the context's device, kept so that destroying the plan never touches the context
     PlanParams pp;
     ofdmtx_plan_sizes sizes;
     // host copies of the layout (ragged); empty for uniform
@@ -1204,6 +1205,7 @@ static void plan_common(ofdmtx_plan *pl, ofdmtx_ctx *ctx, uint64_t n, int pilot_
 {
     memset(&pl->pp, 0, sizeof(pl->pp));
     pl->ctx = ctx;
+    pl->device = ctx->device;
     pl->pp.n_pkts = (uint32_t)n;
     pl->pp.pilot_mode = (uint32_t)pilot_mode;
     pl->pp.pilot_start = pilot_start % 127u;
@@ -1354,7 +1356,7 @@ int ofdmtx_plan_ragged(ofdmtx_ctx *ctx, uint64_t n_pkts, const uint8_t *regimes,
 int ofdmtx_plan_destroy(ofdmtx_plan *pl)
 {
     if (!pl) return OFDMTX_EINVAL;
-    (void)hipSetDevice(pl->ctx->device);
+    (void)hipSetDevice(pl->device);
     if (pl->d_recs) (void)hipFree(pl->d_recs);
     if (pl->d_row_start) (void)hipFree(pl->d_row_start);
     delete pl;
