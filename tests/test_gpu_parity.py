@@ -227,3 +227,23 @@ def test_custom_constellation(txctx, c_oracle):
     with pytest.raises(_lib.OfdmTxError):
         ctx.set_constellation(3, pts)
     ctx.close()
+
+
+@pytest.mark.parametrize("regime", range(1, 9))
+def test_standard_receiver_decodes_gpu_frames(txctx, regime):
+    """A receiver written from the 802.11a standard (tests/rx80211a.py) decodes what the fused
+    kernel emits: SIGNAL parses to the right RATE/LENGTH, the PSDU carries the MAC header and the
+    payload, the FCS checks -- at every rate, uniform and swapped I/Q."""
+    import rx80211a as rx
+    rng = np.random.default_rng(500 + regime)
+    n, ln = 4, 83
+    payloads = rng.integers(0, 256, n * ln, dtype=np.uint8)
+    for flags, swap in ((_lib.F_PREAMBLE | _lib.F_ZEROGAP, False), (_lib.F_PREAMBLE | _lib.F_SWAPIQ, True)):
+        plan = txctx.plan_uniform(n, regime, ln, pilot_start=77, flags=flags, amp=0.5)
+        iq = plan.tx(torch.from_numpy(payloads).to(txctx.device)).cpu().numpy()
+        per = plan.n_samples // n
+        for i in range(n):
+            got = rx.receive(iq[i * per:(i + 1) * per], gain=0.5, swap_iq=swap)
+            assert got["length"] == 24 + ln + 4 and got["fcs_ok"] and not got["service"].any()
+            assert got["psdu"][24:-4] == payloads[i * ln:(i + 1) * ln].tobytes()
+            assert got["psdu"][:2] == b"\x08\x00"

@@ -193,3 +193,20 @@ def test_per_bit_restatement_agrees(regime):
 def test_per_bit_lfsr_is_the_reference_sequence():
     from oracle import ftw_pybits as pb
     assert pb.lfsr_sequence() == list(o.tables().scrambling_seq)
+
+
+# ---- a receiver written from the 802.11a standard decodes what the oracle transmits, at every rate
+
+@pytest.mark.parametrize("regime", [str(r) for r in range(1, 9)])
+def test_standard_receiver_decodes_oracle_frames(regime):
+    import rx80211a as rx
+    rng = np.random.default_rng(300 + int(regime))
+    for n in (0, 61):
+        payload = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        r = o.tx_packet(payload, regime, 4.0, pilot_offset=5, amp=0.3)
+        got = rx.receive(r["iq"], gain=0.3)
+        assert got["length"] == 24 + n + 4 and got["n_sym"] == r["info"]["N_sym"]
+        assert got["rate_bits"] == {"1": 0xD, "2": 0xF, "3": 0x5, "4": 0x7, "5": 0x9, "6": 0xB, "7": 0x1, "8": 0x3}[regime]
+        assert not got["service"].any()
+        assert got["fcs_ok"], "FCS of the decoded PSDU"
+        assert got["psdu"][:24] == r["info"]["packet"][:24] and got["psdu"][24:-4] == payload
