@@ -178,6 +178,12 @@ int ofdmtx_conv_encode(ofdmtx_ctx *ctx, const uint8_t *d_in, uint32_t n_bytes, i
 int ofdmtx_interleave(ofdmtx_ctx *ctx, const uint8_t *d_in, uint32_t n_bytes, int regime,
                       uint8_t *d_out, void *stream);
 
+/* gr.multiply_const_cc(k) on n complex64 samples (the tx_amplitude block of
+ * examples/ftw_ofdm_tx_uhd.py:82-86 when samples are replayed from a file, :75-78); d_in may equal
+ * d_out; both 16-byte aligned. */
+int ofdmtx_scale_cc(ofdmtx_ctx *ctx, const float *d_in, uint64_t n, float k_re, float k_im,
+                    float *d_out, void *stream);
+
 /* ---- variable-size modulator (rawofdm) --------------------------------------------------
  * Stands in for raw.ofdm_mapper (rawofdm/src/lib/ofdm/raw_ofdm.i:18-20,
  * rawofdm/src/lib/ofdm/raw_ofdm_mapper.cc:22-80) and the GNU Radio blocks wired behind it in

@@ -61,6 +61,7 @@ PROTOTYPES = {
     "ofdmtx_scramble": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, _VP, _VP]),
     "ofdmtx_conv_encode": (C.c_int, [_VP, _VP, C.c_uint32, C.c_int, C.c_uint32, _VP, _VP]),
     "ofdmtx_interleave": (C.c_int, [_VP, _VP, C.c_uint32, C.c_int, _VP, _VP]),
+    "ofdmtx_scale_cc": (C.c_int, [_VP, _VP, C.c_uint64, C.c_float, C.c_float, _VP, _VP]),
     "ofdmtx_raw_plan_frames": (C.c_int, [_VP, C.c_uint32, C.c_uint32, _VP, _VP, C.c_uint32, C.c_uint64,
                                          C.c_uint32, C.POINTER(_VP)]),
     "ofdmtx_raw_plan_flags": (C.c_int, [_VP, C.c_uint32, C.c_uint32, _VP, _VP, C.c_uint32, _VP, C.c_uint64,

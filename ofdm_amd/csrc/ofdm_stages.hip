@@ -100,6 +100,24 @@ __global__ void k_stage_interleave(const uint8_t *__restrict__ in, uint8_t *__re
     out[b] = (uint8_t)v;
 }
 
+// gr.multiply_const_cc: out = in * k (complex), 16 bytes per thread
+__global__ void k_scale_cc(const float2 *__restrict__ in, float2 *__restrict__ out, uint64_t n, float kr, float ki)
+{
+    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2u;
+    if (i + 1 < n) {
+        const float4 v = *reinterpret_cast<const float4 *>(in + i);
+        float4 o;
+        o.x = v.x * kr - v.y * ki;
+        o.y = v.x * ki + v.y * kr;
+        o.z = v.z * kr - v.w * ki;
+        o.w = v.z * ki + v.w * kr;
+        *reinterpret_cast<float4 *>(out + i) = o;
+    } else if (i < n) {
+        const float2 v = in[i];
+        out[i] = make_float2(v.x * kr - v.y * ki, v.x * ki + v.y * kr);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -150,6 +168,22 @@ int ofdmtx_interleave(ofdmtx_ctx *ctx, const uint8_t *d_in, uint32_t n_bytes, in
     HIPCHK(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k_stage_interleave, dim3((n_bytes + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, d_in,
                        d_out, n_bytes, r.n_cbps, r.n_bpsc);
+    HIPCHK(hipGetLastError());
+    return OFDMTX_OK;
+}
+
+int ofdmtx_scale_cc(ofdmtx_ctx *ctx, const float *d_in, uint64_t n, float k_re, float k_im, float *d_out,
+                    void *stream)
+{
+    if (!ctx) return OFDMTX_EINVAL;
+    if (n == 0) return OFDMTX_OK;
+    if (!d_in || !d_out) return OFDMTX_EINVAL;
+    if (((uintptr_t)d_in | (uintptr_t)d_out) & 15u) return OFDMTX_EINVAL;      // 16-byte accesses
+    const uint64_t threads = (n + 1) / 2;
+    if ((threads + 255) / 256 > 0x7FFFFFFFull) return OFDMTX_ETOOBIG;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_scale_cc, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float2 *>(d_in), reinterpret_cast<float2 *>(d_out), n, k_re, k_im);
     HIPCHK(hipGetLastError());
     return OFDMTX_OK;
 }

@@ -23,9 +23,10 @@ class my_top_block(gr.top_block):
         else:
             self.sink = gr.null_sink(gr.sizeof_gr_complex)
         options.interp = 100e6 / options.bandwidth          # FTW-specific conversion (ftw_ofdm_tx_uhd.py:71)
-        if getattr(options, "from_file", None) is not None:
-            raise NotImplementedError("--from-file replay needs no modulator; copy the file instead")
-        self.txpath = ftw_transmit_path(options, payload)
+        if getattr(options, "from_file", None) is None:
+            self.txpath = ftw_transmit_path(options, payload)
+        else:
+            self.txpath = gr.file_source(gr.sizeof_gr_complex, options.from_file)
         self._tx_amplitude = options.tx_amplitude
         self.amp = gr.multiply_const_cc(self._tx_amplitude)
         self.connect(self.txpath, self.amp, self.sink)
@@ -63,12 +64,13 @@ def main(argv=None):
     tb = my_top_block(options, my_msg)
     gr.enable_realtime_scheduling()
     tb.start()
-    counter = 0
-    while counter < options.num:
-        tb.txpath.send_pkt(my_msg, eof=False)
-        counter = counter + 1
-    print("End of Transmission")
-    tb.txpath.send_pkt(eof=True)
+    if options.from_file is None:
+        counter = 0
+        while counter < options.num:
+            tb.txpath.send_pkt(my_msg, eof=False)
+            counter = counter + 1
+        print("End of Transmission")
+        tb.txpath.send_pkt(eof=True)
     tb.wait()
     return tb
 

@@ -115,6 +115,45 @@ class file_sink(object):
             self._f = None
 
 
+class file_source(object):
+    """gr.file_source(itemsize, filename): replays raw complex64 samples
+    (examples/ftw_ofdm_tx_uhd.py:75-78) through the connected multiply_const_cc into the sinks, in
+    chunks, on the GPU."""
+
+    def __init__(self, itemsize, filename, repeat=False, chunk_items=1 << 24, device=None):
+        if itemsize != sizeof_gr_complex:
+            raise ValueError("only complex64 streams are replayed")
+        self.filename, self._chunk, self._device = filename, int(chunk_items), device
+        self._gain, self._sinks = None, []
+
+    def _attach(self, gain, sinks):
+        if gain is not None:
+            self._gain = gain
+        self._sinks.extend(sinks)
+
+    def _start(self):
+        pass
+
+    def _finish(self):
+        import ctypes as C
+        import torch
+        from . import _lib
+        from .ftw_packet_utils import _context
+        ctx = _context(self._device)
+        k = complex(self._gain.k()) if self._gain is not None else 1.0 + 0j
+        with open(self.filename, "rb") as f:
+            while True:
+                host = np.fromfile(f, dtype=np.complex64, count=self._chunk)
+                if host.size == 0:
+                    break
+                dev = torch.from_numpy(host).to(ctx.device)
+                stream = C.c_void_p(torch.cuda.current_stream(ctx.device).cuda_stream)
+                _lib.check(ctx._lib.ofdmtx_scale_cc(ctx._h, C.c_void_p(dev.data_ptr()), dev.numel(), k.real, k.imag,
+                                                    C.c_void_p(dev.data_ptr()), stream))
+                for s in self._sinks:
+                    s.write(dev)
+
+
 class null_sink(object):
     def __init__(self, itemsize):
         self.itemsize = itemsize

@@ -272,3 +272,20 @@ def test_cli_main(txctx, tmp_path):
         ref.append(r["iq"])
     got = np.fromfile(out, dtype=np.complex64)
     assert rel_l2_rows(got, np.concatenate(ref)).max() <= REL_L2_TOL
+
+
+@pytest.mark.gpu
+def test_replay_from_file(txctx, tmp_path, monkeypatch):
+    """--log leaves the unit-amplitude stream in ofdm_zerogap.dat (the file the reference's burst
+    replayer reads, my_benchmark_ofdm/tx_file_bursts.cpp:56); --from-file sends it through
+    tx_amplitude again (examples/ftw_ofdm_tx_uhd.py:75-86): same samples as a direct run."""
+    from ofdm_amd import ftw_ofdm, ftw_ofdm_tx
+    monkeypatch.chdir(tmp_path)
+    off0 = ftw_ofdm._pilot_offset[0]
+    ftw_ofdm_tx.main(["--to-file", "direct.dat", "--regime", "6", "-W", "20e6", "-N", "2", "-r", "9", "--log",
+                      "--tx-amplitude", "0.25"])
+    ftw_ofdm_tx.main(["--from-file", "ofdm_zerogap.dat", "--to-file", "replay.dat", "--tx-amplitude", "0.25"])
+    a, b = np.fromfile("direct.dat", np.complex64), np.fromfile("replay.dat", np.complex64)
+    assert a.size == b.size and a.size > 0
+    assert np.array_equal(a, b)              # (x * 0.125) * amp is exact either way: 0.125 is a power of two
+    del off0
