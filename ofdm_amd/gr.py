@@ -97,6 +97,50 @@ def _to_numpy(x):
     return np.ascontiguousarray(x)
 
 
+class _PinnedStager(object):
+    """Device -> host in chunks through two page-locked buffers on a copy stream, so that the copy
+    of chunk i+1 overlaps whatever the consumer does with chunk i (writing it to a file).  A
+    pageable `.cpu()` of the same data runs at a fraction of the link rate."""
+
+    def __init__(self, chunk_bytes=128 << 20):
+        self._chunk = int(chunk_bytes)
+        self._bufs = None
+        self._stream = None
+
+    def chunks(self, t):
+        """Yields numpy views (valid until the next iteration) covering tensor t in order."""
+        import torch
+        flat = t.detach().contiguous().view(torch.uint8).reshape(-1)
+        if not flat.is_cuda:
+            yield flat.numpy()
+            return
+        if self._bufs is None:
+            self._bufs = [torch.empty(self._chunk, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+            self._stream = torch.cuda.Stream(device=flat.device)
+        n = flat.numel()
+        self._stream.wait_stream(torch.cuda.current_stream(flat.device))     # the kernels that produced t
+        events = [None, None]
+
+        def start(i):
+            lo = i * self._chunk
+            hi = min(n, lo + self._chunk)
+            with torch.cuda.stream(self._stream):
+                self._bufs[i & 1][:hi - lo].copy_(flat[lo:hi], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self._stream)
+            events[i & 1] = ev
+            return hi - lo
+
+        n_chunks = (n + self._chunk - 1) // self._chunk
+        size = start(0) if n_chunks else 0
+        for i in range(n_chunks):
+            nxt = start(i + 1) if i + 1 < n_chunks else 0
+            events[i & 1].synchronize()
+            yield self._bufs[i & 1][:size].numpy()
+            size = nxt
+        flat.record_stream(self._stream)
+
+
 class file_sink(object):
     """gr.file_sink(itemsize, filename): raw little-endian items appended to a file
     (examples/ftw_ofdm_tx_uhd.py:66-67: complex64 = float32 I,Q pairs)."""
@@ -105,9 +149,14 @@ class file_sink(object):
         self.itemsize = itemsize
         self.filename = filename
         self._f = open(filename, "wb")
+        self._stager = _PinnedStager()
 
     def write(self, items):
-        _to_numpy(items).tofile(self._f)
+        if hasattr(items, "detach"):
+            for part in self._stager.chunks(items):
+                part.tofile(self._f)
+        else:
+            _to_numpy(items).tofile(self._f)
 
     def close(self):
         if self._f:

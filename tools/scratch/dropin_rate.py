@@ -1,4 +1,4 @@
-"""End-to-end rate of the drop-in path: host payload bytes in (send_pkt), IQ to a host sink."""
+"""End-to-end rate of the drop-in path: host payload bytes in (send_pkt), IQ to a sink."""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
@@ -10,9 +10,10 @@ o.to_file=None; o.from_file=None; o.tx_freq=None
 rng = np.random.default_rng(0)
 n = 100000
 pay = [rng.integers(0,256,1500,dtype=np.uint8).tobytes() for _ in range(64)]
-for sink_kind in ("null", "host"):
+for sink_kind in ("null", "pageable-host", "file:/dev/null", "file:/dev/null"):
+    o.to_file = "/dev/null" if sink_kind.startswith("file") else None
     tb = ftw_ofdm_tx.my_top_block(o, pay[0])
-    if sink_kind == "host":
+    if sink_kind == "pageable-host":
         class HostSink:
             def __init__(s): s.n = 0
             def write(s, t): s.n += t.cpu().numel()
