@@ -38,7 +38,7 @@ def rel_l2_rows(got, ref):
     return np.where(zero, 0.0, num / np.where(zero, 1.0, den))
 
 
-def check_plan(plan, payloads_np, lens, regimes, c_oracle, flags, amp):
+def check_plan(plan, payloads_np, lens, regimes, c_oracle, flags, amp, symbol_time=4.0):
     dev = plan.ctx.device
     payloads = torch.from_numpy(payloads_np).to(dev)
     taps = plan.encode_bits(payloads, taps=True)
@@ -46,7 +46,7 @@ def check_plan(plan, payloads_np, lens, regimes, c_oracle, flags, amp):
     iq2 = plan.tx(payloads)
     torch.cuda.synchronize()
     lay = plan.layout()
-    ref = oracle_batch(c_oracle, payloads_np, lens, regimes, lay["pilot_base"], flags, amp)
+    ref = oracle_batch(c_oracle, payloads_np, lens, regimes, lay["pilot_base"], flags, amp, symbol_time)
     t = {k: v.cpu().numpy() for k, v in taps.items()}
     iq = iq.cpu().numpy()
     iq2 = iq2.cpu().numpy()
@@ -247,3 +247,28 @@ def test_standard_receiver_decodes_gpu_frames(txctx, regime):
             assert got["length"] == 24 + ln + 4 and got["fcs_ok"] and not got["service"].any()
             assert got["psdu"][24:-4] == payloads[i * ln:(i + 1) * ln].tobytes()
             assert got["psdu"][:2] == b"\x08\x00"
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_randomised_plans(txctx, c_oracle, seed):
+    """Random mixes of everything a plan can vary: rates, lengths (edge lengths over-represented),
+    framing flags, pilot mode and start, amplitude, symbol time; ragged and uniform."""
+    rng = np.random.default_rng(9000 + seed)
+    flags = int(rng.integers(0, 8))
+    amp = float(rng.choice([1.0, 0.3, 0.0625, 2.5]))
+    pilot_mode = int(rng.integers(0, 2))
+    pilot_start = int(rng.integers(0, 400))
+    symbol_time = float(rng.choice([4.0, 8.0, 160.0]))
+    n = int(rng.integers(1, 24))
+    edge = np.array([0, 1, 2, 3, 4, 5, 23, 24, 25, 1499, 1500, 1501, 3139, 3140])
+    lens = np.where(rng.random(n) < 0.4, rng.choice(edge, n), rng.integers(0, 600, n)).astype(np.uint32)
+    regs = rng.integers(1, 9, n).astype(np.uint8)
+    payloads = rng.integers(0, 256, int(lens.sum()) + 1, dtype=np.uint8)
+    plan = txctx.plan_ragged(regs, lens, symbol_time=symbol_time, pilot_mode=pilot_mode, pilot_start=pilot_start,
+                             flags=flags, amp=amp)
+    check_plan(plan, payloads, [int(x) for x in lens], [int(r) for r in regs], c_oracle, flags, amp, symbol_time)
+    ln, reg = int(lens[0]), int(regs[0])
+    uni = rng.integers(0, 256, 3 * ln + 1, dtype=np.uint8)
+    plan = txctx.plan_uniform(3, reg, ln, symbol_time=symbol_time, pilot_mode=pilot_mode, pilot_start=pilot_start,
+                              flags=flags, amp=amp)
+    check_plan(plan, uni, [ln] * 3, [reg] * 3, c_oracle, flags, amp, symbol_time)
