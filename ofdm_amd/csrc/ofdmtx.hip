@@ -92,6 +92,7 @@ struct PlanParams {
     // ragged batches
     const PktRec *recs;
     const uint32_t *row_start;    // n_pkts + 1
+    uint32_t *next_pkt;           // work counter of the fused kernel (zeroed before each launch)
     uint32_t total_rows;
     uint32_t flags;
     float amp;
@@ -784,17 +785,20 @@ __device__ __forceinline__ void ifft64_emit(bool active, v2f (&x)[8], int l, int
 // packets have at most 64 DATA symbols (one chunk: U is dead before the first group), otherwise
 // behind it (u_off).
 
-constexpr int TX_WAVES = 8;
+constexpr int TX_WAVES = 8;          // waves per block when two blocks fit a CU's LDS
+constexpr size_t LDS_PER_CU = 160 * 1024;   // gfx950: one workgroup may use all of it
+constexpr int TX_MAX_WAVES = 16;     // launch bound: one block of up to 16 waves otherwise
 constexpr int TX_B_WORDS = 8 * RS * 2;
 
-// (second launch bound = 4 waves per SIMD: caps the kernel at 128 VGPRs; uncapped, hipcc spends
-//  ~250 on the encoder's bit table and halves the occupancy of the whole kernel)
+// (launch bound of 16 waves = 4 per SIMD: caps the kernel at 128 VGPRs; uncapped, hipcc spends
+//  ~250 on the encoder's bit table and halves the occupancy of the whole kernel.  The block size
+//  itself is the launcher's choice: it picks the number of waves the per-wave LDS need allows.)
 //
 // FROM_MSG: the input is not the payloads but the mapper messages k_encode_bits wrote (the
 // two-kernel path, with its taps): the message words take the place of the scrambled words and
 // the slot rows come from message_slots; `mapped` (optional) receives the mapper block's output.
 template <bool UNIFORM, int REGIME, bool FROM_MSG>
-__global__ void __launch_bounds__(64 * TX_WAVES, 4)
+__global__ void __launch_bounds__(64 * TX_MAX_WAVES)
 k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ in, float2 *__restrict__ mapped,
      float2 *__restrict__ iq, uint32_t a_words, uint32_t u_off, uint32_t wave_words)
 {
@@ -808,6 +812,7 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ in, float2 *__restri
     __shared__ uint32_t s_win[8][4];      // per l = lane % 8: slot-row window (see below)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_thr = blockDim.x, n_wv = n_thr >> 6;
     const float amp = P.amp;
     const bool swap_iq = (P.flags & OFDMTX_F_SWAPIQ) != 0;
     if (tid < 64) s_sigc[tid] = slot_code_of(tid, std::make_integer_sequence<int, 4 * SLOT_ROW_WORDS>{});
@@ -833,15 +838,15 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ in, float2 *__restri
     // 1/sqrt(64) (examples/ftw_ofdm.py:126) is a power of two: (x*0.125)*amp == x*(0.125*amp)
     const float scale = 0.125f * amp;
     if constexpr (!FROM_MSG) {
-        for (int i = tid; i < 127; i += 64 * TX_WAVES) s_scr[i] = T.scr_word[i];
-        for (int i = tid; i < 1024; i += 64 * TX_WAVES) s_crc[i] = T.crc_tab[i];
+        for (int i = tid; i < 127; i += n_thr) s_scr[i] = T.scr_word[i];
+        for (int i = tid; i < 1024; i += n_thr) s_crc[i] = T.crc_tab[i];
     }
-    for (int i = tid; i < LUT_SIZE; i += 64 * TX_WAVES) s_lut[i] = T.lut[i];
-    for (int i = tid; i < PRE_ROWS * SYM_LEN; i += 64 * TX_WAVES) {
+    for (int i = tid; i < LUT_SIZE; i += n_thr) s_lut[i] = T.lut[i];
+    for (int i = tid; i < PRE_ROWS * SYM_LEN; i += n_thr) {
         const float2 v = T.preamble[i];                   // pu:508 literals as float32 times tx_amplitude,
         s_pre[i] = swap_iq ? make_float2(v.y * amp, v.x * amp) : make_float2(v.x * amp, v.y * amp);
     }                                                     // I and Q exchanged if asked (examples/ftw_ofdm.py:155-163)
-    for (int i = tid; i < 64; i += 64 * TX_WAVES) {
+    for (int i = tid; i < 64; i += n_thr) {
         const float2 w = T.tw64[((i & 7) * (i >> 3)) & 63];
         s_tw[i] = make_float2(w.x * scale, w.y * scale);
     }
@@ -860,7 +865,19 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ in, float2 *__restri
     const uint32_t gap_rows = (P.flags & OFDMTX_F_ZEROGAP) ? GAP_ROWS : 0;
     const v2f *lut = reinterpret_cast<const v2f *>(s_lut);
 
-    for (uint32_t p = blockIdx.x * TX_WAVES + wave; p < P.n_pkts; p += gridDim.x * TX_WAVES) {
+    // Uniform plans: packets cost the same, a fixed stride balances the waves.  Ragged plans: a
+    // packet's cost follows its symbol count (1 .. 1366 rows), so each wave draws its next packet
+    // from a counter instead (lane 0 asks, the wave reads the answer from lane 0).
+    auto next_packet = [&](uint32_t prev, bool first) -> uint32_t {
+        if constexpr (UNIFORM) {
+            return first ? blockIdx.x * n_wv + wave : prev + gridDim.x * n_wv;
+        } else {
+            uint32_t v = 0;
+            if (lane == 0) v = atomicAdd(P.next_pkt, 1u);
+            return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+        }
+    };
+    for (uint32_t p = next_packet(0, true); p < P.n_pkts; p = next_packet(p, false)) {
         const Pkt k = load_pkt<UNIFORM>(P, p);
         const RegimeInfo ri = regime_info(REGIME ? REGIME : (int)k.regime);
         const size_t row0 = UNIFORM ? (size_t)p * P.rows_per_pkt : (size_t)P.row_start[p];
@@ -1022,7 +1039,8 @@ struct ofdmtx_plan {
     uint32_t *d_row_start;
     ofdmtx_pkt_info uni;   // uniform geometry
     uint32_t tx_a_words;   // LDS words per wave the fused kernel needs for the largest packet (first region)
-    uint32_t tx_u_words;   // ... for the scrambled words of the longest packet
+    uint32_t tx_u_words;   // ... for the scrambled words of the longest packet (payload input)
+    uint32_t tx_m_words;   // ... for the message words of the longest packet (message input)
     uint32_t max_sym_rows; // largest n_sym + 1 of the plan
 };
 
@@ -1185,7 +1203,7 @@ static inline uint32_t align16(uint32_t v) { return (v + 15u) & ~15u; }
 
 // LDS words k_tx needs per wave for a packet: first region = natural MPDU (2 + n_words + 1) or
 // the slot rows of one chunk (+3 words read past the last row's window), whichever is larger;
-// u = the scrambled words (n_words + 2)
+// u = the scrambled words (n_words + 2), or the message words when the input is messages
 static inline uint32_t tx_words_for(const ofdmtx_pkt_info &pi)
 {
     const uint32_t d = (uint32_t)(pi.plcp_len + 3) / 4 + 4;
@@ -1196,8 +1214,11 @@ static inline uint32_t tx_words_for(const ofdmtx_pkt_info &pi)
 }
 static inline uint32_t tx_u_words_for(const ofdmtx_pkt_info &pi)
 {
-    const uint32_t plcp = (uint32_t)(pi.plcp_len + 3) / 4 + 4, msg = (uint32_t)(pi.msg_len + 3) / 4 + 4;
-    return ((plcp > msg ? plcp : msg) + 3u) & ~3u;
+    return ((uint32_t)(pi.plcp_len + 3) / 4 + 4 + 3u) & ~3u;
+}
+static inline uint32_t tx_m_words_for(const ofdmtx_pkt_info &pi)
+{
+    return ((uint32_t)(pi.msg_len + 3) / 4 + 4 + 3u) & ~3u;
 }
 
 static void plan_common(ofdmtx_plan *pl, ofdmtx_ctx *ctx, uint64_t n, int pilot_mode,
@@ -1248,6 +1269,7 @@ int ofdmtx_plan_uniform(ofdmtx_ctx *ctx, uint64_t n_pkts, int regime, uint32_t p
     pl->uni = pi;
     pl->tx_a_words = tx_words_for(pi);
     pl->tx_u_words = tx_u_words_for(pi);
+    pl->tx_m_words = tx_m_words_for(pi);
     pl->max_sym_rows = (uint32_t)pi.n_sym + 1;
     ofdmtx_plan_sizes &sz = pl->sizes;
     sz.n_pkts = n_pkts;
@@ -1278,6 +1300,7 @@ int ofdmtx_plan_ragged(ofdmtx_ctx *ctx, uint64_t n_pkts, const uint8_t *regimes,
     pp.uniform = 0;
     pl->tx_a_words = 16;
     pl->tx_u_words = 16;
+    pl->tx_m_words = 16;
     pl->max_sym_rows = 1;
     pl->recs.resize(n_pkts);
     pl->row_start.resize(n_pkts + 1);
@@ -1296,6 +1319,7 @@ int ofdmtx_plan_ragged(ofdmtx_ctx *ctx, uint64_t n_pkts, const uint8_t *regimes,
         }
         if (tx_words_for(pi) > pl->tx_a_words) pl->tx_a_words = tx_words_for(pi);
         if (tx_u_words_for(pi) > pl->tx_u_words) pl->tx_u_words = tx_u_words_for(pi);
+        if (tx_m_words_for(pi) > pl->tx_m_words) pl->tx_m_words = tx_m_words_for(pi);
         if ((uint32_t)pi.n_sym + 1 > pl->max_sym_rows) pl->max_sym_rows = (uint32_t)pi.n_sym + 1;
         PktRec &r = pl->recs[i];
         memset(&r, 0, sizeof(r));
@@ -1336,7 +1360,9 @@ int ofdmtx_plan_ragged(ofdmtx_ctx *ctx, uint64_t n_pkts, const uint8_t *regimes,
 
     hipError_t e = hipSetDevice(ctx->device);
     if (e == hipSuccess) e = hipMalloc(&pl->d_recs, (n_pkts ? n_pkts : 1) * sizeof(PktRec));
-    if (e == hipSuccess) e = hipMalloc(&pl->d_row_start, (n_pkts + 1) * sizeof(uint32_t));
+    // the fused kernel's work counter sits behind the row table, on a 256-byte line of its own
+    const size_t counter_at = (((size_t)n_pkts + 1) * sizeof(uint32_t) + 255u) & ~(size_t)255u;
+    if (e == hipSuccess) e = hipMalloc(&pl->d_row_start, counter_at + 256);
     if (e == hipSuccess && n_pkts)
         e = hipMemcpy(pl->d_recs, pl->recs.data(), n_pkts * sizeof(PktRec), hipMemcpyHostToDevice);
     if (e == hipSuccess)
@@ -1349,6 +1375,7 @@ int ofdmtx_plan_ragged(ofdmtx_ctx *ctx, uint64_t n_pkts, const uint8_t *regimes,
     }
     pp.recs = pl->d_recs;
     pp.row_start = pl->d_row_start;
+    pp.next_pkt = pl->d_row_start + counter_at / sizeof(uint32_t);
     *out = pl;
     return OFDMTX_OK;
 }
@@ -1458,21 +1485,37 @@ static int launch_tx(ofdmtx_ctx *ctx, const ofdmtx_plan *pl, const uint8_t *d_in
     // a region of their own
     const bool one_chunk = pl->max_sym_rows <= 65u;
     const uint32_t a_words = pl->tx_a_words;
-    const uint32_t u_off = one_chunk ? a_words : a_words + (uint32_t)TX_B_WORDS;
-    const uint32_t wave_words = a_words + (uint32_t)TX_B_WORDS + (one_chunk ? 0u : pl->tx_u_words);
-    const size_t lds = (size_t)TX_WAVES * wave_words * sizeof(uint32_t);
-    const int grid = grid_for(ctx, pl->pp.n_pkts, TX_WAVES, 2);
+    const uint32_t own_words = FROM_MSG ? pl->tx_m_words : pl->tx_u_words;
+    // in one chunk the staging area must still hold them
+    const uint32_t b_words = one_chunk && own_words > (uint32_t)TX_B_WORDS ? ((own_words + 3u) & ~3u) : (uint32_t)TX_B_WORDS;
+    const uint32_t u_off = one_chunk ? a_words : a_words + b_words;
+    const uint32_t wave_words = a_words + b_words + (one_chunk ? 0u : own_words);
     const PlanParams &pp = pl->pp;
     const DevTables tab = ctx->tables();
-    // a workgroup may use more than the default 64 KiB of LDS only after asking for it
+    // Waves per block: 8 when two such blocks fit the CU's LDS, otherwise as many (up to 16) as
+    // one block can hold.  A workgroup may use more than the default 64 KiB only after asking.
 #define LAUNCH_TX(U_, R_)                                                                            \
     do {                                                                                             \
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tx<U_, R_, FROM_MSG>),          \
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));           \
-        hipLaunchKernelGGL((k_tx<U_, R_, FROM_MSG>), dim3(grid), dim3(64 * TX_WAVES), lds, st, pp,   \
+        const void *fn = reinterpret_cast<const void *>(&k_tx<U_, R_, FROM_MSG>);                    \
+        hipFuncAttributes fa;                                                                        \
+        HIPCHK(hipFuncGetAttributes(&fa, fn));                                                       \
+        const size_t wave_bytes = (size_t)wave_words * sizeof(uint32_t);                             \
+        const size_t room = LDS_PER_CU > fa.sharedSizeBytes ? LDS_PER_CU - fa.sharedSizeBytes : 0; \
+        int waves = TX_WAVES, per_cu = 2;                                                            \
+        if (2 * (TX_WAVES * wave_bytes + fa.sharedSizeBytes) > LDS_PER_CU) {                    \
+            waves = (int)(room / wave_bytes);                                                        \
+            waves = waves > TX_MAX_WAVES ? TX_MAX_WAVES : waves;                                     \
+            per_cu = 1;                                                                              \
+        }                                                                                            \
+        if (waves < 1) return OFDMTX_ETOOBIG;                                                        \
+        const size_t lds = (size_t)waves * wave_bytes;                                               \
+        const int grid = grid_for(ctx, pl->pp.n_pkts, waves, per_cu);                                \
+        HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));       \
+        hipLaunchKernelGGL((k_tx<U_, R_, FROM_MSG>), dim3(grid), dim3(64 * waves), lds, st, pp,      \
                            tab, d_in, mapped, iq, a_words, u_off, wave_words);                       \
     } while (0)
     if (!pp.uniform) {
+        HIPCHK(hipMemsetAsync(pp.next_pkt, 0, sizeof(uint32_t), st));
         LAUNCH_TX(false, 0);
     } else if (FROM_MSG) {
         // the message path does not depend on the code rate: one instantiation per constellation
