@@ -47,12 +47,23 @@ extern "C" {
 #define OFDMTX_F_PREAMBLE 1u  /* prepend the 4x80-sample preamble (ftw/ftw_ofdm_preamble.cc:79-83) */
 #define OFDMTX_F_ZEROGAP 2u   /* append 13x80 zero samples (ftw/ftw_zerogap.cc:88-92)              */
 #define OFDMTX_F_SWAPIQ 4u    /* swap re/im (examples/ftw_ofdm.py:155-163)                         */
+/* PNC roles (examples/ftw_ofdm.py:133-138, ftw/ftw_pnc_ofdm_preamble.cc:80-103): with
+ * OFDMTX_F_PREAMBLE, SIX preamble rows -- the two short-training rows, then the two long-training
+ * rows followed (role A, user 1) or preceded (role B, user 2) by two rows of zeros.  At most one
+ * of the two; the zero gap is the same 13 rows (ftw/ftw_pnc_zerogap.cc:88-92). */
+#define OFDMTX_F_PNC_A 8u
+#define OFDMTX_F_PNC_B 16u
 
 /* pilot polarity index of symbol s of packet q */
 #define OFDMTX_PILOT_REF_STREAM 0 /* running counter over the whole stream, as the reference's
                                      process-global counter does (ftw/ftw_ofdm_pilot_cc.cc:82,159):
                                      pilot_start + sum_{r<q}(N_sym_r+1) + s                        */
 #define OFDMTX_PILOT_PER_PACKET 1 /* restart at pilot_start for every packet (the standard)        */
+/* the PNC pilot block (ftw/ftw_pnc_ofdm_pilot_cc.cc:125-131,146-178): constant pilots at
+ * -21, -7, +7, +21, no polarity sequence, no sign change at +21; pilot_start is ignored */
+#define OFDMTX_PILOT_PNC_A 2      /* user 1: +1  0 +1  0                                           */
+#define OFDMTX_PILOT_PNC_B 3      /* user 2:  0 +1  0 +1                                           */
+#define OFDMTX_PILOT_PNC_ALL 4    /* user 0: +1 +1 +1 +1                                           */
 
 typedef struct ofdmtx_ctx ofdmtx_ctx;
 typedef struct ofdmtx_plan ofdmtx_plan;
@@ -186,6 +197,13 @@ int ofdmtx_interleave(ofdmtx_ctx *ctx, const uint8_t *d_in, uint32_t n_bytes, in
  * d_out; both 16-byte aligned. */
 int ofdmtx_scale_cc(ofdmtx_ctx *ctx, const float *d_in, uint64_t n, float k_re, float k_im,
                     float *d_out, void *stream);
+
+/* ftw.repetition (ftw/ftw.i:143-146, ftw/ftw_repetition.cc:54-76): the block copies rows from its
+ * input without ever consuming them, i.e. it emits the first packet of its input (period =
+ * (N_symbols + 5 + 13) * symbol_length samples) again and again.  d_out[i] = d_in[i % period]
+ * for i < n_out (complex64 samples; period and n_out even, buffers 16-byte aligned). */
+int ofdmtx_repeat(ofdmtx_ctx *ctx, const float *d_in, uint64_t period, uint64_t n_out, float *d_out,
+                  void *stream);
 
 /* ---- variable-size modulator (rawofdm) --------------------------------------------------
  * Stands in for raw.ofdm_mapper (rawofdm/src/lib/ofdm/raw_ofdm.i:18-20,

@@ -12,8 +12,8 @@ LIB_PATH = os.environ.get("OFDMTX_LIB", os.path.join(_HERE, "libofdmtx.so"))
 
 OK = 0
 EINVAL, EREGIME, ELENGTH, EHIP, ENOMEM, ESHAPE, ETOOBIG = -1, -2, -3, -4, -5, -6, -7
-F_PREAMBLE, F_ZEROGAP, F_SWAPIQ = 1, 2, 4
-PILOT_REF_STREAM, PILOT_PER_PACKET = 0, 1
+F_PREAMBLE, F_ZEROGAP, F_SWAPIQ, F_PNC_A, F_PNC_B = 1, 2, 4, 8, 16
+PILOT_REF_STREAM, PILOT_PER_PACKET, PILOT_PNC_A, PILOT_PNC_B, PILOT_PNC_ALL = 0, 1, 2, 3, 4
 
 
 class OfdmTxError(RuntimeError):
@@ -62,6 +62,7 @@ PROTOTYPES = {
     "ofdmtx_conv_encode": (C.c_int, [_VP, _VP, C.c_uint32, C.c_int, C.c_uint32, _VP, _VP]),
     "ofdmtx_interleave": (C.c_int, [_VP, _VP, C.c_uint32, C.c_int, _VP, _VP]),
     "ofdmtx_scale_cc": (C.c_int, [_VP, _VP, C.c_uint64, C.c_float, C.c_float, _VP, _VP]),
+    "ofdmtx_repeat": (C.c_int, [_VP, _VP, C.c_uint64, C.c_uint64, _VP, _VP]),
     "ofdmtx_raw_plan_frames": (C.c_int, [_VP, C.c_uint32, C.c_uint32, _VP, _VP, C.c_uint32, C.c_uint64,
                                          C.c_uint32, C.POINTER(_VP)]),
     "ofdmtx_raw_plan_flags": (C.c_int, [_VP, C.c_uint32, C.c_uint32, _VP, _VP, C.c_uint32, _VP, C.c_uint64,

@@ -118,6 +118,17 @@ __global__ void k_scale_cc(const float2 *__restrict__ in, float2 *__restrict__ o
     }
 }
 
+// ftw/ftw_repetition.cc:54-76: the block never consumes its input, so its output is the first
+// `period` input rows over and over.  16 bytes per thread; blockIdx.y walks the copies, so no
+// thread computes a remainder.
+__global__ void k_repeat(const float4 *__restrict__ in, float4 *__restrict__ out, uint64_t period4, uint64_t total4)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= period4) return;
+    const float4 v = in[j];
+    for (uint64_t o = (uint64_t)blockIdx.y * period4 + j; o < total4; o += (uint64_t)gridDim.y * period4) out[o] = v;
+}
+
 }  // namespace
 
 extern "C" {
@@ -184,6 +195,29 @@ int ofdmtx_scale_cc(ofdmtx_ctx *ctx, const float *d_in, uint64_t n, float k_re, 
     HIPCHK(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k_scale_cc, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const float2 *>(d_in), reinterpret_cast<float2 *>(d_out), n, k_re, k_im);
+    HIPCHK(hipGetLastError());
+    return OFDMTX_OK;
+}
+
+int ofdmtx_repeat(ofdmtx_ctx *ctx, const float *d_in, uint64_t period, uint64_t n_out, float *d_out, void *stream)
+{
+    if (!ctx) return OFDMTX_EINVAL;
+    if (n_out == 0) return OFDMTX_OK;
+    if (!d_in || !d_out || period == 0) return OFDMTX_EINVAL;
+    // whole 16-byte pieces: even sample counts (rows of 80 samples always are), aligned buffers
+    if ((period & 1u) || (n_out & 1u) || (((uintptr_t)d_in | (uintptr_t)d_out) & 15u)) return OFDMTX_EINVAL;
+    const uint64_t period4 = period / 2, total4 = n_out / 2;
+    const uint64_t bx = (period4 + 255) / 256;
+    if (bx > 0x7FFFFFFFull) return OFDMTX_ETOOBIG;
+    uint64_t copies = (total4 + period4 - 1) / period4;
+    // enough blocks to fill the GPU, at most 65535 in y
+    const uint64_t want_y = ((uint64_t)ctx->n_cu * 16 + bx - 1) / bx;
+    uint64_t by = copies < want_y ? copies : want_y;
+    if (by > 65535) by = 65535;
+    if (by < 1) by = 1;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_repeat, dim3((unsigned)bx, (unsigned)by), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4 *>(d_in), reinterpret_cast<float4 *>(d_out), period4, total4);
     HIPCHK(hipGetLastError());
     return OFDMTX_OK;
 }

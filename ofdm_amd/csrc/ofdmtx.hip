@@ -39,7 +39,8 @@ constexpr int MAXLEN = 3168;          // pu:119
 constexpr int MAX_PLCP = 3264;        // 5 + 3168 + 28 tail/pad bytes, rounded up to 64
 constexpr int SYM_LEN = 80;           // examples/ftw_ofdm.py:75
 constexpr int PRE_ROWS = 4;           // ftw/ftw_ofdm_preamble.cc:79
-constexpr int GAP_ROWS = 13;          // ftw/ftw_zerogap.cc:88
+constexpr int PNC_PRE_ROWS = 6;       // ftw/ftw_pnc_ofdm_preamble.cc:81-107
+constexpr int GAP_ROWS = 13;          // ftw/ftw_zerogap.cc:88, ftw/ftw_pnc_zerogap.cc:88
 // Constellation LUT slots (complex entries).  Every table starts at a power of two at least
 // its size, so that slot = offset | index:
 //   0 zero (null carriers) | 2 (-1,0), 3 (+1,0): SIGNAL BPSK and the pilots | 4,5 BPSK | 8..11 QPSK
@@ -336,9 +337,14 @@ __device__ __forceinline__ void encode_data_symbols(const uint32_t *U, uint32_t 
 // U: >= n_words + 2 words.  plcp_out / scr_out are optional taps (global memory).
 __device__ __forceinline__ void scramble_packet(const Pkt &k, const RegimeInfo &ri, const DevTables &T,
                                                 const uint8_t *__restrict__ payloads, uint32_t *A, uint32_t *U,
-                                                const uint32_t *s_crc, const uint32_t *s_scr, int lane,
+                                                const uint32_t *s_crc, const uint32_t *s_scr, int lane_in,
                                                 uint8_t *plcp_out, uint8_t *scr_out)
 {
+    // Opaque copy of the lane number: in a uniform plan every per-lane address below is invariant
+    // over the caller's packet loop; hoisted out of it, they would take registers that the
+    // encoder needs and come back as scratch reloads, which wait for every store in flight.
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
     const uint32_t mpdu_len = 24u + k.pay_len;
     const uint32_t length = mpdu_len + 4u;                                   // pu:193
     const uint32_t n_pad = k.n_sym * ri.n_dbps - (54u + 8u * mpdu_len);      // pu:97
@@ -531,6 +537,33 @@ __device__ __forceinline__ int slot_code_of(int rb, std::integer_sequence<int, R
 }
 
 constexpr int lut_off_for(int nbpsc) { return nbpsc == 1 ? 4 : nbpsc == 2 ? 8 : nbpsc == 4 ? 16 : 64; }
+
+// ftw/ftw_pnc_ofdm_pilot_cc.cc:125-131,146-178: the PNC pilot block writes constant pilots, no
+// polarity sequence.  As a "pilot pack": one slot byte (0 = zero, LUT_PM1 + 1 = +1) per pilot
+// in the order +7, +21, -21, -7 (FFT bins 7, 21, 43, 57).
+constexpr int pilot_bin(int i) { return i == 0 ? 7 : i == 1 ? 21 : i == 2 ? 43 : 57; }
+constexpr uint32_t PILOTS_PNC_A = ((LUT_PM1 + 1u) << 0) | ((LUT_PM1 + 1u) << 16);      // user 1: -21 and +7 carry +1
+constexpr uint32_t PILOTS_PNC_B = ((LUT_PM1 + 1u) << 8) | ((LUT_PM1 + 1u) << 24);      // user 2: -7 and +21
+constexpr uint32_t PILOTS_PNC_ALL = PILOTS_PNC_A | PILOTS_PNC_B;                       // user 0
+
+constexpr int slot_row_byte_of(int bin)       // inverse of slot_row_bin
+{
+    for (int rb = 0; rb < 4 * SLOT_ROW_WORDS; rb++)
+        if (slot_row_bin(rb) == bin) return rb;
+    return 0;
+}
+
+// Overwrites the four pilot bytes of one slot row with a pilot pack.
+template <int... I>
+__device__ __forceinline__ void set_row_pilots(uint32_t *row, uint32_t pack, std::integer_sequence<int, I...>)
+{
+    uint8_t *b = reinterpret_cast<uint8_t *>(row);
+    ((b[std::integral_constant<int, slot_row_byte_of(pilot_bin(I))>::value] = (uint8_t)(pack >> (8 * I))), ...);
+}
+__device__ __forceinline__ void set_row_pilots(uint32_t *row, uint32_t pack)
+{
+    set_row_pilots(row, pack, std::make_integer_sequence<int, 4>{});
+}
 
 // ftw/ftw_ofdm_pilot_cc.cc:116,159: polarity of the pilots of the symbol with running index pidx
 __device__ __forceinline__ uint32_t pilot_negative(uint32_t pidx, uint64_t pneg_lo, uint64_t pneg_hi)
@@ -797,7 +830,11 @@ constexpr int TX_B_WORDS = 8 * RS * 2;
 // FROM_MSG: the input is not the payloads but the mapper messages k_encode_bits wrote (the
 // two-kernel path, with its taps): the message words take the place of the scrambled words and
 // the slot rows come from message_slots; `mapped` (optional) receives the mapper block's output.
-template <bool UNIFORM, int REGIME, bool FROM_MSG>
+//
+// PNC: the instantiations for plans with a PNC role (six-row preamble patterns, constant pilots).
+// They are separate so that the standard ones keep their register allocation; they dispatch
+// the regime per packet (REGIME = 0).
+template <bool UNIFORM, int REGIME, bool FROM_MSG, bool PNC = false>
 __global__ void __launch_bounds__(64 * TX_MAX_WAVES)
 k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ in, float2 *__restrict__ mapped,
      float2 *__restrict__ iq, uint32_t a_words, uint32_t u_off, uint32_t wave_words)
@@ -806,7 +843,7 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ in, float2 *__restri
     __shared__ uint32_t s_crc[FROM_MSG ? 1 : 1024];
     __shared__ uint32_t s_scr[FROM_MSG ? 1 : 128];
     __shared__ float2 s_lut[LUT_SIZE];
-    __shared__ __align__(16) float2 s_pre[PRE_ROWS * SYM_LEN];
+    __shared__ __align__(16) float2 s_pre[(PNC ? PNC_PRE_ROWS : PRE_ROWS) * SYM_LEN];   // preamble rows, amplitude applied
     __shared__ float2 s_tw[64];
     __shared__ int s_sigc[64];            // SIGNAL row: bin_code of the bin behind row byte i (-1: none)
     __shared__ uint32_t s_win[8][4];      // per l = lane % 8: slot-row window (see below)
@@ -842,10 +879,23 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ in, float2 *__restri
         for (int i = tid; i < 1024; i += n_thr) s_crc[i] = T.crc_tab[i];
     }
     for (int i = tid; i < LUT_SIZE; i += n_thr) s_lut[i] = T.lut[i];
-    for (int i = tid; i < PRE_ROWS * SYM_LEN; i += n_thr) {
-        const float2 v = T.preamble[i];                   // pu:508 literals as float32 times tx_amplitude,
-        s_pre[i] = swap_iq ? make_float2(v.y * amp, v.x * amp) : make_float2(v.x * amp, v.y * amp);
-    }                                                     // I and Q exchanged if asked (examples/ftw_ofdm.py:155-163)
+    if constexpr (PNC) {
+        // Row r of the packet's preamble = table row (pre_map >> 4r) & 15, or zeros (15).  The PNC
+        // roles (ftw/ftw_pnc_ofdm_preamble.cc:80-103) send the two short-training rows, then the
+        // two long-training rows followed (A) or preceded (B) by two zero rows.
+        const uint32_t pre_map = (P.flags & OFDMTX_F_PNC_B) ? 0x32FF10u : 0xFF3210u;
+        for (int i = tid; i < PNC_PRE_ROWS * SYM_LEN; i += n_thr) {
+            const uint32_t r = (uint32_t)i / SYM_LEN, src = (pre_map >> (4u * r)) & 15u;
+            float2 v = make_float2(0.f, 0.f);
+            if (src < (uint32_t)PRE_ROWS) v = T.preamble[src * SYM_LEN + (uint32_t)i - r * SYM_LEN];
+            s_pre[i] = swap_iq ? make_float2(v.y * amp, v.x * amp) : make_float2(v.x * amp, v.y * amp);
+        }
+    } else {
+        for (int i = tid; i < PRE_ROWS * SYM_LEN; i += n_thr) {
+            const float2 v = T.preamble[i];               // pu:508 literals as float32 times tx_amplitude,
+            s_pre[i] = swap_iq ? make_float2(v.y * amp, v.x * amp) : make_float2(v.x * amp, v.y * amp);
+        }                                                 // I and Q exchanged if asked (examples/ftw_ofdm.py:155-163)
+    }
     for (int i = tid; i < 64; i += n_thr) {
         const float2 w = T.tw64[((i & 7) * (i >> 3)) & 63];
         s_tw[i] = make_float2(w.x * scale, w.y * scale);
@@ -861,7 +911,14 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ in, float2 *__restri
     uint64_t pneg_hi = T.pilot_neg[2] | ((uint64_t)T.pilot_neg[3] << 32);
     asm volatile("" : "+s"(pneg_lo), "+s"(pneg_hi));
 
-    const uint32_t pre_rows = (P.flags & OFDMTX_F_PREAMBLE) ? PRE_ROWS : 0;
+    uint32_t pre_rows = (P.flags & OFDMTX_F_PREAMBLE) ? PRE_ROWS : 0;
+    uint32_t pilots_fixed = 0;
+    if constexpr (PNC) {
+        if (pre_rows && (P.flags & (OFDMTX_F_PNC_A | OFDMTX_F_PNC_B))) pre_rows = PNC_PRE_ROWS;
+        pilots_fixed = P.pilot_mode == OFDMTX_PILOT_PNC_A ? PILOTS_PNC_A
+                     : P.pilot_mode == OFDMTX_PILOT_PNC_B ? PILOTS_PNC_B
+                     : P.pilot_mode == OFDMTX_PILOT_PNC_ALL ? PILOTS_PNC_ALL : 0u;
+    }
     const uint32_t gap_rows = (P.flags & OFDMTX_F_ZEROGAP) ? GAP_ROWS : 0;
     const v2f *lut = reinterpret_cast<const v2f *>(s_lut);
 
@@ -901,6 +958,9 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ in, float2 *__restri
         if (pre_rows) {
             const float4 *pre4 = reinterpret_cast<const float4 *>(s_pre);
             for (uint32_t i = lane; i < PRE_ROWS * SYM_LEN / 2; i += 64) out[i] = pre4[i];
+            if constexpr (PNC)
+                if (pre_rows > (uint32_t)PRE_ROWS)        // PNC roles: two more rows
+                    for (uint32_t i = PRE_ROWS * SYM_LEN / 2 + lane; i < PNC_PRE_ROWS * SYM_LEN / 2; i += 64) out[i] = pre4[i];
         }
         if (gap_rows) {
             float4 *gp = out + (size_t)(pre_rows + sym_rows) * (SYM_LEN / 2);
@@ -954,6 +1014,14 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ in, float2 *__restri
                 case 7: symbol_slots<6, 2>(U, rows, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
                 default: symbol_slots<6, 1>(U, rows, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
                 }
+            }
+            if (PNC && pilots_fixed) {
+                // PNC pilot block: the rows just built carry the polarity-sequence pilots;
+                // each lane replaces them in its own DATA row, lane 0 also in the SIGNAL row
+                int lane_p = lane;                        // opaque: keeps these addresses out of the encoder's way
+                asm volatile("" : "+v"(lane_p));
+                if (d0 + (uint32_t)lane_p < k.n_sym) set_row_pilots(rows + SLOT_ROW_WORDS * lane_p, pilots_fixed);
+                if (d0 == 0 && lane_p == 0) set_row_pilots(SI, pilots_fixed);
             }
             wave_sync();
 
@@ -1094,7 +1162,7 @@ int ofdmtx_packet_info(int regime, int payload_len, double symbol_time, unsigned
     out->length = mpdu + 4;
     out->plcp_len = 5 + out->length + (out->n_pad + 6 + 7) / 8;         // pu:160-171,205
     out->msg_len = 6 + out->n_sym * ri.n_cbps / 8;
-    out->n_rows = ((flags & OFDMTX_F_PREAMBLE) ? PRE_ROWS : 0) + 1 + out->n_sym +
+    out->n_rows = ((flags & OFDMTX_F_PREAMBLE) ? ((flags & (OFDMTX_F_PNC_A | OFDMTX_F_PNC_B)) ? PNC_PRE_ROWS : PRE_ROWS) : 0) + 1 + out->n_sym +
                   ((flags & OFDMTX_F_ZEROGAP) ? GAP_ROWS : 0);
     // the length limit is ftw_make's (pu:119-121), get_info itself has none: *out is complete either way
     return mpdu + 4 > MAXLEN ? OFDMTX_ELENGTH : OFDMTX_OK;
@@ -1221,6 +1289,15 @@ static inline uint32_t tx_m_words_for(const ofdmtx_pkt_info &pi)
     return ((uint32_t)(pi.msg_len + 3) / 4 + 4 + 3u) & ~3u;
 }
 
+static bool plan_modes_ok(int pilot_mode, unsigned flags)
+{
+    if (pilot_mode < OFDMTX_PILOT_REF_STREAM || pilot_mode > OFDMTX_PILOT_PNC_ALL) return false;
+    const unsigned roles = flags & (OFDMTX_F_PNC_A | OFDMTX_F_PNC_B);
+    if (roles == (OFDMTX_F_PNC_A | OFDMTX_F_PNC_B)) return false;       // one role at a time
+    if (roles && !(flags & OFDMTX_F_PREAMBLE)) return false;            // the role only shapes the preamble
+    return true;
+}
+
 static void plan_common(ofdmtx_plan *pl, ofdmtx_ctx *ctx, uint64_t n, int pilot_mode,
                         uint32_t pilot_start, unsigned flags, float amp)
 {
@@ -1242,7 +1319,7 @@ int ofdmtx_plan_uniform(ofdmtx_ctx *ctx, uint64_t n_pkts, int regime, uint32_t p
 {
     if (!ctx || !out) return OFDMTX_EINVAL;
     *out = nullptr;
-    if (pilot_mode != OFDMTX_PILOT_REF_STREAM && pilot_mode != OFDMTX_PILOT_PER_PACKET)
+    if (!plan_modes_ok(pilot_mode, flags))
         return OFDMTX_EINVAL;
     if (payload_len > (uint32_t)MAXLEN) return OFDMTX_ELENGTH;
     ofdmtx_pkt_info pi;
@@ -1290,7 +1367,7 @@ int ofdmtx_plan_ragged(ofdmtx_ctx *ctx, uint64_t n_pkts, const uint8_t *regimes,
 {
     if (!ctx || !out || (n_pkts && (!regimes || !payload_len))) return OFDMTX_EINVAL;
     *out = nullptr;
-    if (pilot_mode != OFDMTX_PILOT_REF_STREAM && pilot_mode != OFDMTX_PILOT_PER_PACKET)
+    if (!plan_modes_ok(pilot_mode, flags))
         return OFDMTX_EINVAL;
     if (n_pkts >= 0xFFFFFFF0ull) return OFDMTX_ETOOBIG;
     ofdmtx_plan *pl = new (std::nothrow) ofdmtx_plan();
@@ -1494,9 +1571,9 @@ static int launch_tx(ofdmtx_ctx *ctx, const ofdmtx_plan *pl, const uint8_t *d_in
     const DevTables tab = ctx->tables();
     // Waves per block: 8 when two such blocks fit the CU's LDS, otherwise as many (up to 16) as
     // one block can hold.  A workgroup may use more than the default 64 KiB only after asking.
-#define LAUNCH_TX(U_, R_)                                                                            \
+#define LAUNCH_TX(U_, R_, ...)                                                                       \
     do {                                                                                             \
-        const void *fn = reinterpret_cast<const void *>(&k_tx<U_, R_, FROM_MSG>);                    \
+        const void *fn = reinterpret_cast<const void *>(&k_tx<U_, R_, FROM_MSG, ##__VA_ARGS__>);     \
         hipFuncAttributes fa;                                                                        \
         HIPCHK(hipFuncGetAttributes(&fa, fn));                                                       \
         const size_t wave_bytes = (size_t)wave_words * sizeof(uint32_t);                             \
@@ -1511,11 +1588,14 @@ static int launch_tx(ofdmtx_ctx *ctx, const ofdmtx_plan *pl, const uint8_t *d_in
         const size_t lds = (size_t)waves * wave_bytes;                                               \
         const int grid = grid_for(ctx, pl->pp.n_pkts, waves, per_cu);                                \
         HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));       \
-        hipLaunchKernelGGL((k_tx<U_, R_, FROM_MSG>), dim3(grid), dim3(64 * waves), lds, st, pp,      \
+        hipLaunchKernelGGL((k_tx<U_, R_, FROM_MSG, ##__VA_ARGS__>), dim3(grid), dim3(64 * waves), lds, st, pp, \
                            tab, d_in, mapped, iq, a_words, u_off, wave_words);                       \
     } while (0)
-    if (!pp.uniform) {
-        HIPCHK(hipMemsetAsync(pp.next_pkt, 0, sizeof(uint32_t), st));
+    const bool pnc = (pp.flags & (OFDMTX_F_PNC_A | OFDMTX_F_PNC_B)) || pp.pilot_mode >= OFDMTX_PILOT_PNC_A;
+    if (!pp.uniform) HIPCHK(hipMemsetAsync(pp.next_pkt, 0, sizeof(uint32_t), st));
+    if (pnc) {
+        if (pp.uniform) LAUNCH_TX(true, 0, true); else LAUNCH_TX(false, 0, true);
+    } else if (!pp.uniform) {
         LAUNCH_TX(false, 0);
     } else if (FROM_MSG) {
         // the message path does not depend on the code rate: one instantiation per constellation

@@ -50,6 +50,23 @@ class ofdm_pilot_cc(object):
             raise RuntimeError("ftw_ofdm_pilot_cc: IEEE 802.11p requires 48 subcarriers\n")
 
 
+class pnc_ofdm_pilot_cc(object):
+    """ftw.i:66-68, ftw_pnc_ofdm_pilot_cc.cc:125-131,146-178: constant pilots at -21, -7, +7, +21 --
+    user 1: (1, 0, 1, 0); any other non-zero user: (0, 1, 0, 1); user 0: (1, 1, 1, 1).  No
+    polarity sequence and no sign change on the fourth pilot."""
+
+    def __init__(self, tones, user):
+        self.tones, self.user = tones, int(user)
+
+    def check(self):
+        if self.tones != 48:                                        # :121-122
+            raise RuntimeError("ftw_pnc_ofdm_pilot_cc: IEEE 802.11p requires 48 subcarriers\n")
+
+    @property
+    def pilot_mode(self):
+        return {1: _lib.PILOT_PNC_A, 0: _lib.PILOT_PNC_ALL}.get(self.user, _lib.PILOT_PNC_B)
+
+
 class ofdm_cmap_cc(object):
     """ftw.i:42-50; ftw_ofdm_cmap_cc.cc:97-99."""
 
@@ -70,9 +87,60 @@ class ofdm_preamble(object):
         self.preamble = [list(p) for p in preamble]
 
 
+class pnc_ofdm_preamble(object):
+    """ftw.i:94-106, ftw_pnc_ofdm_preamble.cc:80-107: six rows in front of every packet -- the two
+    short-training rows of the table, then its two long-training rows followed (user 1) or
+    preceded (user 2) by two rows of zeros."""
+
+    def __init__(self, symbol_length, N_symbols, preamble, user):
+        if int(user) not in (1, 2):                                 # :105 only prints an error
+            raise RuntimeError("ERROR: user not set properly! [FTW_PNC_PREAMBLE]")
+        self.symbol_length, self.N_symbols, self.user = symbol_length, N_symbols, int(user)
+        self.preamble = [list(p) for p in preamble]
+
+    @property
+    def flags(self):
+        return _lib.F_PREAMBLE | (_lib.F_PNC_A if self.user == 1 else _lib.F_PNC_B)
+
+
 class zerogap(object):
     """ftw.i:110-122, ftw_zerogap.cc:39-102: 13 rows of zeros behind every packet."""
 
     def __init__(self, symbol_length, N_symbols, gap):
         self.symbol_length, self.N_symbols = symbol_length, N_symbols
         self.gap = [list(g) for g in gap]
+
+
+class pnc_zerogap(zerogap):
+    """ftw.i:126-138, ftw_pnc_zerogap.cc:39-102: passes N_symbols + 7 rows (six preamble rows and
+    the SIGNAL symbol more than DATA symbols), then the same 13 rows of zeros."""
+
+
+class repetition(object):
+    """ftw.i:143-146, ftw_repetition.cc:40-76: emits the first packet of its input -- (N_symbols +
+    5 + 13) rows of symbol_length samples -- over and over (the block never consumes input; its
+    `repetition` argument is unused, :72-74 is commented out)."""
+
+    def __init__(self, symbol_length, repetition, N_symbols):
+        self.symbol_length, self.repetition_count, self.N_symbols = int(symbol_length), repetition, int(N_symbols)
+
+    @property
+    def period(self):
+        return (self.N_symbols + 5 + 13) * self.symbol_length
+
+    def work(self, in_samples, noutput_items, ctx=None, stream=None):
+        """in_samples: complex64 device tensor holding at least one period; returns noutput_items
+        rows (noutput_items * symbol_length samples)."""
+        import torch
+        from . import ftw_packet_utils
+        if in_samples.dtype != torch.complex64 or not in_samples.is_contiguous():
+            raise TypeError("repetition: contiguous complex64 tensor expected")
+        if in_samples.numel() < self.period:
+            raise ValueError("repetition: input shorter than one packet (%d samples)" % self.period)
+        ctx = ctx or ftw_packet_utils._context(in_samples.device.index)
+        n_out = int(noutput_items) * self.symbol_length
+        out = torch.empty(n_out, dtype=torch.complex64, device=in_samples.device)
+        st = stream if stream is not None else torch.cuda.current_stream(in_samples.device).cuda_stream
+        _lib.check(_lib.load().ofdmtx_repeat(ctx._h, in_samples.data_ptr(), self.period, n_out,
+                                             out.data_ptr(), st))
+        return out

@@ -25,7 +25,8 @@ _pilot_offset = [0]
 class ofdm_mod(gr.hier_block2):
     """examples/ftw_ofdm.py:45-219.
 
-    options: regime (str "1".."8"), interp, swapIQ, log, role (None only).  batch_packets bounds
+    options: regime (str "1".."8"), interp, swapIQ, log, role (None, 'A' or 'B': the PNC pilot,
+    preamble and zero-gap blocks of :101-106,133-138,147-149).  batch_packets bounds
     how many queued packets are modulated per kernel launch."""
 
     def __init__(self, options, payload='', msgq_limit=2, pad_for_usrp=False, batch_packets=65536, device=None):
@@ -37,8 +38,6 @@ class ofdm_mod(gr.hier_block2):
         self._regime = str(options.regime)
         self._symbol_length = self._fft_length + self._cp_length
         self._role = getattr(options, "role", None)
-        if self._role is not None:
-            raise NotImplementedError("PNC role %r is outside this library's scope" % (self._role,))
         # examples/ftw_ofdm.py:81 (Python 2 `/`: interp is a float there, ftw_ofdm_tx_uhd.py:71)
         self._symbol_time = options.interp * (self._fft_length + self._cp_length) / 100
 
@@ -51,15 +50,26 @@ class ofdm_mod(gr.hier_block2):
 
         # the blocks of examples/ftw_ofdm.py:98-149: parameter holders, checked as the C++ blocks check
         self._pkt_input = ftw.ofdm_mapper(rotated_const, msgq_limit, self._data_subcarriers, self._fft_length)
-        self.pilot = ftw.ofdm_pilot_cc(self._data_subcarriers)
+        if self._role == 'A':                                        # examples/ftw_ofdm.py:101-109
+            self.pilot = ftw.pnc_ofdm_pilot_cc(self._data_subcarriers, 1)
+        elif self._role == 'B':
+            self.pilot = ftw.pnc_ofdm_pilot_cc(self._data_subcarriers, 2)
+        else:
+            self.pilot = ftw.ofdm_pilot_cc(self._data_subcarriers)
         self.cmap = ftw.ofdm_cmap_cc(self._fft_length, self._total_sub_carriers)
         self.pilot.check()
         self.cmap.check()
         self.scale = gr.multiply_const_cc(1.0 / math.sqrt(self._fft_length))
         info = ofdm_packet_utils.get_info(payload, options.regime, self._symbol_time)
         N_sym = info["N_sym"]
-        self.preamble = ofdm_packet_utils.insert_preamble(self._symbol_length, N_sym)
-        self.zerogap = ofdm_packet_utils.insert_zerogap(self._symbol_length, N_sym)
+        if self._role in ('A', 'B'):                                 # examples/ftw_ofdm.py:133-149
+            self.preamble = ofdm_packet_utils.insert_preamble(self._symbol_length, N_sym, self._role)
+        else:
+            self.preamble = ofdm_packet_utils.insert_preamble(self._symbol_length, N_sym)
+        if self._role is None:
+            self.zerogap = ofdm_packet_utils.insert_zerogap(self._symbol_length, N_sym)
+        else:
+            self.zerogap = ofdm_packet_utils.insert_zerogap(self._symbol_length, N_sym, 'FPNC')
 
         self._swap = bool(getattr(options, "swapIQ", False))
         self._log = bool(getattr(options, "log", False))
@@ -112,16 +122,19 @@ class ofdm_mod(gr.hier_block2):
         pk, self._pending = self._pending, []
         ctx = self._ctx
         amp = float(self._gain.k()) if self._gain is not None else 1.0
-        flags = _lib.F_PREAMBLE | _lib.F_ZEROGAP | (_lib.F_SWAPIQ if self._swap else 0)
+        flags = (getattr(self.preamble, "flags", _lib.F_PREAMBLE) | _lib.F_ZEROGAP |
+                 (_lib.F_SWAPIQ if self._swap else 0))
+        pilot_mode = getattr(self.pilot, "pilot_mode", _lib.PILOT_REF_STREAM)
         lens = np.fromiter((len(p) for p in pk), dtype=np.uint32, count=len(pk))
         start = _pilot_offset[0] % 127
 
         def make_plan(a):
             if np.all(lens == lens[0]):
                 return ctx.plan_uniform(len(pk), int(self._regime), int(lens[0]), symbol_time=self._symbol_time,
-                                        pilot_start=start, flags=flags, amp=a)
+                                        pilot_mode=pilot_mode, pilot_start=start, flags=flags, amp=a)
             return ctx.plan_ragged(np.full(len(pk), int(self._regime), np.uint8), lens,
-                                   symbol_time=self._symbol_time, pilot_start=start, flags=flags, amp=a)
+                                   symbol_time=self._symbol_time, pilot_mode=pilot_mode, pilot_start=start,
+                                   flags=flags, amp=a)
 
         plan = make_plan(amp)
         _pilot_offset[0] += plan.n_symbols

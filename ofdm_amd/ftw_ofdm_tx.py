@@ -53,13 +53,16 @@ def make_parser():
                       help="set number of HelloWorld in single packet to send, [default=%default]")
     parser.add_option("-p", "--payload", type="string", default=None,
                       help="payload ASCII-string to send, [default=%default]")
-    parser.add_option("-R", "--role", type="string", default=None, help="PNC role (not supported)")
+    parser.add_option("-R", "--role", type="string", default=None, help="PNC role: A or B [default=%default]")
     return parser
 
 
 def main(argv=None):
     (options, args) = make_parser().parse_args(argv)
-    options.payload = "HelloWorld" * options.repeat         # ftw_ofdm_tx_uhd.py:143-148
+    if options.role == 'B':                                 # ftw_ofdm_tx_uhd.py:143-148
+        options.payload = "WorldHello" * options.repeat
+    else:
+        options.payload = "HelloWorld" * options.repeat
     my_msg = options.payload
     tb = my_top_block(options, my_msg)
     gr.enable_realtime_scheduling()

@@ -151,17 +151,21 @@ def gen_and_append_crc32(MPDU, packet_for_crc):
 
 
 def insert_preamble(length, N_sym, role=None):
-    """pu:374-383 (the PNC roles are not part of this library)."""
-    if role is not None:
-        raise NotImplementedError("PNC role %r is outside this library's scope" % (role,))
-    return ftw.ofdm_preamble(length, N_sym, [list(fft_preamble)])
+    """pu:374-383."""
+    ftw_preamble = [list(fft_preamble)]
+    if role == 'A':
+        return ftw.pnc_ofdm_preamble(length, N_sym, ftw_preamble, 1)
+    if role == 'B':
+        return ftw.pnc_ofdm_preamble(length, N_sym, ftw_preamble, 2)
+    return ftw.ofdm_preamble(length, N_sym, ftw_preamble)
 
 
 def insert_zerogap(length, N_sym, state='FTW'):
     """pu:385-392."""
-    if state != 'FTW':
-        raise NotImplementedError("zerogap state %r is outside this library's scope" % (state,))
-    return ftw.zerogap(length, N_sym, [list(gap_sample)])
+    gap = [list(gap_sample)]
+    if state == 'FPNC':
+        return ftw.pnc_zerogap(length, N_sym, gap)
+    return ftw.zerogap(length, N_sym, gap)
 
 
 def qam16(self):

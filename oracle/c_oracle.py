@@ -99,7 +99,7 @@ def modulate(msg, regime, pilot_offset=0, amp=0.3, flags=3):
     regime = int(regime)
     n_cbps = (48, 48, 96, 96, 192, 192, 288, 288)[regime - 1]
     n_sym = (len(msg) - 6) * 8 // n_cbps
-    rows = (4 if flags & 1 else 0) + 1 + n_sym + (13 if flags & 2 else 0)
+    rows = ((6 if flags & 24 else 4) if flags & 1 else 0) + 1 + n_sym + (13 if flags & 2 else 0)
     mapped = np.zeros((1 + n_sym, 48), np.complex64)
     iq = np.zeros(rows * 80, np.complex64)
     iq64 = np.zeros(rows * 80, np.complex128)

@@ -237,7 +237,9 @@ static void ifft64(const double *xr, const double *xi, double *yr, double *yi)
 
 /*
  * Mapper message -> IQ (ftw_ofdm.py:175-179 flowgraph).  flags: bit0 preamble, bit1 zero
- * gap, bit2 swap I/Q.  mapped_out (optional): (1+N_sym)*48 complex64 (re,im floats).
+ * gap, bit2 swap I/Q; bit3 / bit4: the six-row preamble of PNC role A / B
+ * (ftw/ftw_pnc_ofdm_preamble.cc:80-103); bits 8-10: pilot block, 0 = ftw_ofdm_pilot_cc,
+ * 2 / 3 / 4 = ftw_pnc_ofdm_pilot_cc with user 1 / 2 / 0 (ftw/ftw_pnc_ofdm_pilot_cc.cc:125-131).  mapped_out (optional): (1+N_sym)*48 complex64 (re,im floats).
  * iq_out: complex64 samples; iq64_out (optional): the same values before the float cast.
  * Returns the number of complex samples written.
  */
@@ -254,7 +256,17 @@ int orc_modulate(const orc_tables *t, const uint8_t *msg, int msg_len, int regim
         if (flags & 4) { double t__ = re__; re__ = im__; im__ = t__; } \
         if (iq_out) { iq_out[2 * o] = (float)re__; iq_out[2 * o + 1] = (float)im__; } \
         if (iq64_out) { iq64_out[2 * o] = re__; iq64_out[2 * o + 1] = im__; } o++; } while (0)
-    if (flags & 1)                                            /* ftw/ftw_ofdm_preamble.cc:79-83 */
+    if ((flags & 1) && (flags & (8 | 16))) {
+        /* ftw/ftw_pnc_ofdm_preamble.cc:80-103: the two short-training rows, then the two
+         * long-training rows before (user 1) or after (user 2) two rows of zeros */
+        static const int rows_a[6] = {0, 1, 2, 3, -1, -1}, rows_b[6] = {0, 1, -1, -1, 2, 3};
+        const int *rows = (flags & 8) ? rows_a : rows_b;
+        for (int r = 0; r < 6; r++)
+            for (int i = 0; i < 80; i++) {
+                if (rows[r] < 0) PUT(0.0, 0.0);
+                else PUT(t->preamble[2 * (80 * rows[r] + i)] * a, t->preamble[2 * (80 * rows[r] + i) + 1] * a);
+            }
+    } else if (flags & 1)                                     /* ftw/ftw_ofdm_preamble.cc:79-83 */
         for (int i = 0; i < 320; i++) PUT(t->preamble[2 * i] * a, t->preamble[2 * i + 1] * a);
     for (int sym = 0; sym <= n_sym; sym++) {
         float d[48][2];
@@ -278,11 +290,17 @@ int orc_modulate(const orc_tables *t, const uint8_t *msg, int msg_len, int regim
         if (mapped_out) memcpy(mapped_out + (long)sym * 96, d, sizeof d);
         /* pilots ftw/ftw_ofdm_pilot_cc.cc:113-158, carrier map ftw/ftw_ofdm_cmap_cc.cc:101-109 */
         double p = t->pol[(sym + pilot_offset) % 127];
+        double pv[4] = {p, p, p, -p};                         /* carriers -21, -7, +7, +21 */
+        const int pilot_block = (flags >> 8) & 7;
+        if (pilot_block) {                                    /* ftw/ftw_pnc_ofdm_pilot_cc.cc:125-131,146-178 */
+            const int a_ = pilot_block == 2, b_ = pilot_block == 3, all = pilot_block == 4;
+            pv[0] = pv[2] = (a_ || all) ? 1.0 : 0.0;
+            pv[1] = pv[3] = (b_ || all) ? 1.0 : 0.0;
+        }
         double c53r[53], c53i[53];
         int di = 0;
         for (int i = 0; i < 53; i++) {
-            if (i == 5 || i == 19 || i == 33) { c53r[i] = p; c53i[i] = 0; }
-            else if (i == 47) { c53r[i] = -p; c53i[i] = 0; }
+            if (i == 5 || i == 19 || i == 33 || i == 47) { c53r[i] = pv[i == 5 ? 0 : i == 19 ? 1 : i == 33 ? 2 : 3]; c53i[i] = 0; }
             else if (i == 26) { c53r[i] = 0; c53i[i] = 0; }
             else { c53r[i] = d[di][0]; c53i[i] = d[di][1]; di++; }
         }

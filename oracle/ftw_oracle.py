@@ -323,25 +323,44 @@ def ofdm_mapper(msg, regime):
 
 # --------------------------------------------------------------------------- a12/a13: pilots, carrier map
 
-def ofdm_pilot(sym48, pilot_offset=0):
+def ofdm_pilot(sym48, pilot_offset=0, user=None):
     """ftw_ofdm_pilot_cc.cc:86-166: 48 -> 53 carriers; symbol c uses polarity[(c+offset)%127].
-    `pilot_offset` models the block's process-global running counter (:82,:159)."""
+    `pilot_offset` models the block's process-global running counter (:82,:159).
+    user 1 / 2 / 0: ftw_pnc_ofdm_pilot_cc.cc:125-131,146-178 instead -- the same carrier layout
+    with constant pilots (1,0,1,0) / (0,1,0,1) / (1,1,1,1) at -21, -7, +7, +21, no polarity
+    sequence and no sign change on the fourth."""
     sym48 = np.asarray(sym48)
     n = sym48.shape[0]
     out = np.zeros((n, 53), dtype=np.complex64)
-    p = tables().pilot_polarity[(np.arange(n) + pilot_offset) % 127].astype(np.float32)
+    if user is None:
+        p = tables().pilot_polarity[(np.arange(n) + pilot_offset) % 127].astype(np.float32)
+        pv = [p, p, p, -p]
+    else:
+        pv = {1: [1, 0, 1, 0], 0: [1, 1, 1, 1]}.get(user, [0, 1, 0, 1])      # :127 "if (d_user != 1)"
     out[:, 0:5] = sym48[:, 0:5]
-    out[:, 5] = p
+    out[:, 5] = pv[0]
     out[:, 6:19] = sym48[:, 5:18]
-    out[:, 19] = p
+    out[:, 19] = pv[1]
     out[:, 20:26] = sym48[:, 18:24]
     out[:, 26] = 0
     out[:, 27:33] = sym48[:, 24:30]
-    out[:, 33] = p
+    out[:, 33] = pv[2]
     out[:, 34:47] = sym48[:, 30:43]
-    out[:, 47] = -p
+    out[:, 47] = pv[3]
     out[:, 48:53] = sym48[:, 43:48]
     return out
+
+
+def pnc_preamble(user):
+    """ftw_pnc_ofdm_preamble.cc:80-103: six rows -- the two short-training rows of the table,
+    then its two long-training rows followed (user 1) or preceded (user 2) by two zero rows."""
+    rows = tables().fft_preamble.reshape(4, SYM_LEN)
+    z = np.zeros((2, SYM_LEN), dtype=rows.dtype)
+    if user == 1:
+        return np.concatenate([rows[0:2], rows[2:4], z]).reshape(-1)
+    if user == 2:
+        return np.concatenate([rows[0:2], z, rows[2:4]]).reshape(-1)
+    raise ValueError("user must be 1 or 2")                        # :105 prints an error and emits garbage
 
 
 def ofdm_cmap(sym53):
@@ -380,10 +399,13 @@ def assemble_ppdu(sym80, amp=0.3, swap_iq=False):
     return s
 
 
-def modulate(msg, regime, pilot_offset=0, amp=0.3, swap_iq=False, preamble=True, zerogap=True):
-    """Mapper message -> per-stage arrays, following the flowgraph of ftw_ofdm.py:175-179."""
+def modulate(msg, regime, pilot_offset=0, amp=0.3, swap_iq=False, preamble=True, zerogap=True, role=None):
+    """Mapper message -> per-stage arrays, following the flowgraph of ftw_ofdm.py:175-179.
+    role 'A' / 'B': the PNC blocks of ftw_ofdm.py:101-106,133-138,147-149 (pilot and preamble
+    blocks with user 1 / 2; ftw_pnc_zerogap.cc:81-92 appends the same 13 zero rows)."""
+    user = {None: None, "A": 1, "B": 2}[role]
     mapped, flags = ofdm_mapper(msg, regime)
-    pil = ofdm_pilot(mapped, pilot_offset)
+    pil = ofdm_pilot(mapped, pilot_offset, user)
     bins = ofdm_cmap(pil)
     x = ifft_unnormalised(bins)
     cp = cyclic_prefix(x, CP_LEN)
@@ -391,7 +413,7 @@ def modulate(msg, regime, pilot_offset=0, amp=0.3, swap_iq=False, preamble=True,
     t = tables()
     parts = []
     if preamble:
-        parts.append(t.fft_preamble)
+        parts.append(t.fft_preamble if user is None else pnc_preamble(user))
     parts.append(scaled.reshape(-1))
     if zerogap:
         parts.append(np.zeros(N_GAP_ROWS * SYM_LEN, dtype=np.complex128))
@@ -404,10 +426,10 @@ def modulate(msg, regime, pilot_offset=0, amp=0.3, swap_iq=False, preamble=True,
 
 
 def tx_packet(payload, regime, symboltime=4.0, pilot_offset=0, amp=0.3, swap_iq=False,
-              preamble=True, zerogap=True):
+              preamble=True, zerogap=True, role=None):
     """Whole chain for one payload: send_pkt (ftw_ofdm.py:191-219) + flowgraph + top-level amp."""
     enc = encode_bits(payload, regime, symboltime)
-    mod = modulate(enc["interleaved"], regime, pilot_offset, amp, swap_iq, preamble, zerogap)
+    mod = modulate(enc["interleaved"], regime, pilot_offset, amp, swap_iq, preamble, zerogap, role)
     enc.update(mod)
     return enc
 

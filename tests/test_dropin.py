@@ -254,8 +254,52 @@ def test_send_pkt_rejects_long_payload(txctx):
     mod = ftw_ofdm.ofdm_mod(Options(regime="1", interp=5.0), b"")
     with pytest.raises(ValueError):
         mod.send_pkt(b"\x00" * 3141)
-    with pytest.raises(NotImplementedError):
-        ftw_ofdm.ofdm_mod(Options(regime="1", interp=5.0, role="A"), b"")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("role,regime", [("A", "1"), ("B", "1"), ("A", "6"), ("B", "8")])
+def test_pnc_roles_cli(txctx, tmp_path, role, regime):
+    """--role A / B (examples/ftw_ofdm_tx_uhd.py:143-148, examples/ftw_ofdm.py:101-106,133-149):
+    the PNC pilot, preamble and zero-gap blocks; role B sends "WorldHello"."""
+    from ofdm_amd import ftw_ofdm_tx
+    out = str(tmp_path / "pnc.dat")
+    ftw_ofdm_tx.main(["--to-file", out, "--regime", regime, "-W", "20e6", "-N", "3", "-r", "11", "--role", role])
+    payload = (b"HelloWorld" if role == "A" else b"WorldHello") * 11
+    one = fo.tx_packet(payload, regime, 4.0, amp=0.3, role=role)
+    assert one["iq"].size == 80 * (6 + 1 + one["info"]["N_sym"] + 13)
+    got = np.fromfile(out, dtype=np.complex64)
+    # constant pilots: every packet of the stream is the same
+    assert rel_l2_rows(got, np.tile(one["iq"], 3)).max() <= REL_L2_TOL
+
+
+@pytest.mark.gpu
+def test_pnc_blocks_and_repetition(txctx):
+    from ofdm_amd import _lib, ftw, ftw_packet_utils as pu
+    import torch
+    assert isinstance(pu.insert_preamble(80, 10, 'A'), ftw.pnc_ofdm_preamble)
+    assert pu.insert_preamble(80, 10, 'B').flags == _lib.F_PREAMBLE | _lib.F_PNC_B
+    assert type(pu.insert_preamble(80, 10)) is ftw.ofdm_preamble
+    assert isinstance(pu.insert_zerogap(80, 10, 'FPNC'), ftw.pnc_zerogap)
+    assert type(pu.insert_zerogap(80, 10)) is ftw.zerogap
+    assert [ftw.pnc_ofdm_pilot_cc(48, u).pilot_mode for u in (1, 2, 0)] == [_lib.PILOT_PNC_A, _lib.PILOT_PNC_B,
+                                                                           _lib.PILOT_PNC_ALL]
+    with pytest.raises(RuntimeError):
+        ftw.pnc_ofdm_pilot_cc(52, 1).check()
+    with pytest.raises(RuntimeError):
+        ftw.pnc_ofdm_preamble(80, 10, [list(pu.fft_preamble)], 3)
+    # ftw.repetition: the first (N_sym + 18) rows of the input, again and again
+    n_sym = 7
+    rep = ftw.repetition(80, 0, n_sym)
+    assert rep.period == 80 * 25
+    rng = np.random.default_rng(9)
+    src = (rng.standard_normal(80 * 60) + 1j * rng.standard_normal(80 * 60)).astype(np.complex64)
+    dev = torch.from_numpy(src).to(txctx.device)
+    for rows in (1, 25, 26, 100, 1003):
+        got = rep.work(dev, rows).cpu().numpy()
+        want = np.tile(src[:rep.period], rows // 25 + 1)[:80 * rows]
+        assert np.array_equal(got, want), rows
+    with pytest.raises(ValueError):
+        rep.work(dev[:100], 5)
 
 
 @pytest.mark.gpu

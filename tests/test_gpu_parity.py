@@ -199,6 +199,44 @@ def test_side_stream(txctx):
     assert torch.equal(got2.view(torch.float32), ref.view(torch.float32))
 
 
+@pytest.mark.parametrize("role", ["A", "B"])
+def test_pnc_roles(txctx, c_oracle, role):
+    """PNC role plans (ftw/ftw_pnc_ofdm_preamble.cc:80-103, ftw/ftw_pnc_ofdm_pilot_cc.cc:125-178):
+    six preamble rows, constant pilots; all rates, uniform and ragged, one chunk and several,
+    fused and two-kernel paths, I/Q swap."""
+    pf = _lib.F_PNC_A if role == "A" else _lib.F_PNC_B
+    pm = _lib.PILOT_PNC_A if role == "A" else _lib.PILOT_PNC_B
+    rng = np.random.default_rng(31)
+    for regime, ln in [(1, 40), (2, 700), (3, 333), (4, 1), (5, 1500), (6, 0), (7, 2000), (8, 1500), (8, 3140)]:
+        flags = _lib.F_PREAMBLE | _lib.F_ZEROGAP | pf | (_lib.F_SWAPIQ if regime == 6 else 0)
+        payloads = rng.integers(0, 256, 3 * ln, dtype=np.uint8)
+        plan = txctx.plan_uniform(3, regime, ln, pilot_mode=pm, flags=flags, amp=0.3)
+        assert plan.n_samples == 3 * 80 * (6 + 1 + _lib.packet_info(regime, ln).n_sym + 13)
+        check_plan(plan, payloads, [ln] * 3, [regime] * 3, c_oracle, flags | (pm << 8), 0.3)
+    n = 60
+    regs = rng.integers(1, 9, n).astype(np.uint8)
+    lens = rng.integers(0, 1200, n).astype(np.uint32)
+    payloads = rng.integers(0, 256, int(lens.sum()), dtype=np.uint8)
+    flags = _lib.F_PREAMBLE | _lib.F_ZEROGAP | pf
+    plan = txctx.plan_ragged(regs, lens, pilot_mode=pm, flags=flags, amp=0.7)
+    check_plan(plan, payloads, lens.tolist(), regs.tolist(), c_oracle, flags | (pm << 8), 0.7)
+
+
+def test_pnc_mode_combinations(txctx, c_oracle):
+    """Pilot block and preamble role are independent plan parameters: constant pilots with the
+    standard preamble, no preamble at all, the all-ones pilot block (user 0); bad combinations."""
+    rng = np.random.default_rng(32)
+    ln = 500
+    payloads = rng.integers(0, 256, 2 * ln, dtype=np.uint8)
+    for pm, flags in [(_lib.PILOT_PNC_ALL, 3), (_lib.PILOT_PNC_A, 2), (_lib.PILOT_PNC_B, 0),
+                      (_lib.PILOT_REF_STREAM, 1 | 2 | _lib.F_PNC_A), (_lib.PILOT_PER_PACKET, 1 | _lib.F_PNC_B)]:
+        plan = txctx.plan_uniform(2, 5, ln, pilot_mode=pm, pilot_start=3, flags=flags, amp=0.3)
+        check_plan(plan, payloads, [ln] * 2, [5] * 2, c_oracle, flags | ((pm if pm >= 2 else 0) << 8), 0.3)
+    for pm, flags in [(5, 3), (-1, 3), (0, 3 | _lib.F_PNC_A | _lib.F_PNC_B), (0, 2 | _lib.F_PNC_A)]:
+        with pytest.raises(_lib.OfdmTxError):
+            txctx.plan_uniform(2, 5, ln, pilot_mode=pm, flags=flags)
+
+
 def test_ragged_plan_reuse(txctx, c_oracle):
     """A ragged plan's waves draw packets from a counter the launcher resets: many more packets
     than waves, launched repeatedly (default stream, then a side stream), give the same samples

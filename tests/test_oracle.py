@@ -210,3 +210,49 @@ def test_standard_receiver_decodes_oracle_frames(regime):
         assert not got["service"].any()
         assert got["fcs_ok"], "FCS of the decoded PSDU"
         assert got["psdu"][:24] == r["info"]["packet"][:24] and got["psdu"][24:-4] == payload
+
+
+# ---- PNC roles (ftw_pnc_ofdm_preamble.cc:80-103, ftw_pnc_ofdm_pilot_cc.cc:125-178, ftw_pnc_zerogap.cc:81-92)
+
+@pytest.mark.parametrize("role", ["A", "B"])
+def test_pnc_role_frames(role, c_oracle):
+    """Structure of a PNC frame, checked on the samples: six preamble rows with the long-training
+    pair before (A) or after (B) two zero rows; constant pilots 1,0,1,0 / 0,1,0,1 at -21,-7,+7,+21
+    on every symbol, SIGNAL included; 13 zero rows behind; the data carriers are those of the
+    standard frame.  The C and numpy restatements agree."""
+    import rx80211a as rx
+    rng = np.random.default_rng(77)
+    payload = rng.integers(0, 256, 200, dtype=np.uint8).tobytes()
+    for regime in ("1", "6", "8"):
+        std = o.tx_packet(payload, regime, 4.0, pilot_offset=9, amp=0.3)
+        pnc = o.tx_packet(payload, regime, 4.0, pilot_offset=9, amp=0.3, role=role)
+        n_sym = std["info"]["N_sym"]
+        rows = pnc["iq"].reshape(-1, 80)
+        srows = std["iq"].reshape(-1, 80)
+        assert rows.shape[0] == 6 + 1 + n_sym + 13 and srows.shape[0] == 4 + 1 + n_sym + 13
+        lts, zero = (slice(2, 4), slice(4, 6)) if role == "A" else (slice(4, 6), slice(2, 4))
+        assert np.array_equal(rows[0:2], srows[0:2]) and np.array_equal(rows[lts], srows[2:4])
+        assert not rows[zero].any() and not rows[-13:].any()
+        spec = np.fft.fft(rows[6:6 + 1 + n_sym, 16:], axis=1) / (8 * float(np.float32(0.3)))
+        sspec = np.fft.fft(srows[4:4 + 1 + n_sym, 16:], axis=1) / (8 * float(np.float32(0.3)))
+        want = {"A": (1, 0, 1, 0), "B": (0, 1, 0, 1)}[role]
+        for f, w in zip((-21, -7, 7, 21), want):
+            assert np.allclose(spec[:, f % 64], w, atol=1e-9)
+        data = [f % 64 for f in rx.DATA_FREQS]
+        assert np.allclose(spec[:, data], sspec[:, data], atol=1e-9)
+        # a standard receiver skips the two extra rows and decodes the frame (it does not use pilots)
+        got = rx.receive(pnc["iq"][160:], gain=0.3)
+        assert got["fcs_ok"] and got["psdu"][24:-4] == payload
+        flags = 3 | (8 if role == "A" else 16) | ((2 if role == "A" else 3) << 8)
+        c = c_oracle.modulate(std["interleaved"], int(regime), 9, 0.3, flags)
+        assert np.allclose(c["iq64"], pnc["iq"], atol=1e-12)
+
+
+def test_pnc_pilot_block_user_0():
+    """user 0 fills all four pilots with +1 (ftw_pnc_ofdm_pilot_cc.cc:130-131); any user other
+    than 0 and 1 behaves as user 2 (:127)."""
+    sym = np.zeros((3, 48), np.complex64)
+    for user, want in ((0, (1, 1, 1, 1)), (1, (1, 0, 1, 0)), (2, (0, 1, 0, 1)), (7, (0, 1, 0, 1))):
+        p = o.ofdm_pilot(sym, 0, user)
+        assert [p[1, i].real for i in (5, 19, 33, 47)] == list(want)
+        assert not np.delete(p, (5, 19, 33, 47), axis=1).any()
