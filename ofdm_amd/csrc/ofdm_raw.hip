@@ -265,6 +265,7 @@ struct QamTxParams {
     uint32_t ncarriers, nsymbols, qambits, nc, np;
     uint32_t cbps;             // qambits * ncarriers
     uint64_t n_values;         // n_frames * nsymbols * ncarriers
+    uint64_t total_bytes;      // n_frames * frame_bytes
     float scale;               // PAM level spacing / 2 (rawofdm/src/lib/qam/raw_qam.cc:39-52)
 };
 
@@ -381,6 +382,249 @@ __global__ void __launch_bounds__(256) k_raw_qam_tx(QamTxParams Q, const uint8_t
                 lv[a] = (float)pt * Q.scale;
             }
             out[(row0 + r) * Q.ncarriers + car] = make_float2(lv[0], lv[1]);
+        }
+    }
+}
+
+// ---- the table entries of rawofdm/src/python/raw_qam.py:19-28: structure instead of a per-bit map
+//
+// rawofdm/src/lib/qam/raw_conv.cc:150-159 keeps the first np of every nc coded bits; on MSB-first
+// words that is a fixed compaction.
+__device__ __forceinline__ uint32_t keep_3_of_4(uint32_t x)      // 32 bits -> 24 bits, left-aligned
+{
+    const uint32_t y = (x & 0xE0E0E0E0u) | ((x & 0x0E0E0E0Eu) << 1);      // 6 bits at the top of each byte
+    const uint32_t z = (y & 0xFC00FC00u) | ((y & 0x00FC00FCu) << 2);      // 12 bits at the top of each half
+    return (z & 0xFFF00000u) | ((z & 0x0000FFF0u) << 4);
+}
+__device__ __forceinline__ uint32_t keep_4_of_6(uint32_t c)      // 24 bits (right-aligned) -> 16 bits
+{
+    return ((c >> 8) & 0xF000u) | ((c >> 6) & 0x0F00u) | ((c >> 4) & 0x00F0u) | ((c >> 2) & 0x000Fu);
+}
+
+// The bit interleaver (rawofdm/src/lib/qam/raw_intrlv.cc:22-30) on a symbol of cbps punctured
+// bits is a 16-column block interleaver followed by a rotation inside groups of s bits:
+// with col = cbps / 16 and the punctured stream read as 16-bit units H[m] (MSB first),
+// position i = col * b + m holds bit b of H[m]; position j of the output takes
+// i = s*(j/s) + ((j % s) + b) % s, b = i / col being the same for a whole group because s
+// divides col.  A group of s bits is one axis of one carrier (raw_qam.cc:63-74: I, then Q), so a
+// carrier's axis reads s neighbouring units at ONE bit position: s 16-bit LDS reads and a shift
+// each, against a table look-up, two divisions and a word read per bit in the general kernel.
+// Walks idx = tid, tid + 256, .. as (row, column) pairs of rows `width` wide without dividing
+// inside the loop.
+struct RowWalk {
+    uint32_t r, x, dr, dx, width;
+    __device__ __forceinline__ RowWalk(uint32_t tid, uint32_t step, uint32_t w)
+        : r(tid / w), x(tid % w), dr(step / w), dx(step % w), width(w) {}
+    __device__ __forceinline__ void next()
+    {
+        r += dr;
+        x += dx;
+        if (x >= width) { x -= width; r++; }
+    }
+};
+
+// GROUPED (ncarriers a multiple of 16): a thread takes the QB units behind carriers c', c' + G,
+// .. c' + 15 G (G = ncarriers / 16) -- they are the 16 bit positions of the same units -- so every
+// bit position, rotation and shift below is a compile-time constant.
+template <int QB, int S, int B>
+__device__ __forceinline__ uint32_t axis_index(const uint32_t (&h)[QB == 1 ? 1 : QB], int a)
+{
+    // output bit t of the group is stream bit (t + b) % S of the group; first bit = MSB
+    uint32_t idx = 0;
+#pragma unroll
+    for (int t = 0; t < S; t++) idx |= ((h[a * S + (t + B) % S] >> (15 - B)) & 1u) << (S - 1 - t);
+    return idx;
+}
+
+// one byte per carrier value: (I index << 3) | Q index
+template <int QB, int S, int... B>
+__device__ __forceinline__ void emit_unit_group(const uint32_t (&h)[QB == 1 ? 1 : QB], uint8_t *dst, uint32_t g,
+                                                std::integer_sequence<int, B...>)
+{
+    ((dst[(uint32_t)B * g] = (uint8_t)((axis_index<QB, S, B>(h, 0) << 3) |
+                                       (QB == 1 ? 0u : axis_index<QB, S, B>(h, QB == 1 ? 0 : 1)))), ...);
+}
+
+template <int QB, int NC, int NP, bool GROUPED>
+__global__ void __launch_bounds__(256) k_raw_qam_tx_fast(QamTxParams Q, const uint8_t *__restrict__ data,
+                                                         float2 *__restrict__ out, uint32_t in_stride,
+                                                         uint32_t cod_stride, uint32_t pun_stride,
+                                                         uint32_t rows_per_iter)
+{
+    constexpr uint32_t S = QB / 2 > 1 ? QB / 2 : 1;              // group size = bits per axis
+    constexpr uint32_t AXES = QB == 1 ? 1 : 2;
+    extern __shared__ uint32_t s_qam[];
+    uint32_t *s_in = s_qam;                                       // frame bytes behind the rows, MSB-first words
+    uint32_t *s_cod = s_in + in_stride * rows_per_iter;           // coded bits of the rows, MSB first
+    uint32_t *s_pun = NP == NC ? s_cod : s_cod + cod_stride * rows_per_iter;
+    const uint32_t p_stride = NP == NC ? cod_stride : pun_stride;
+    uint32_t *s_row = s_cod + cod_stride * rows_per_iter + (NP == NC ? 0u : pun_stride * rows_per_iter);   // 4 words per row
+    uint16_t *s_g = reinterpret_cast<uint16_t *>(s_row + 4u * rows_per_iter);
+    // GROUPED: no group table; the level indices of the pass, one byte per carrier value
+    uint8_t *s_idx = reinterpret_cast<uint8_t *>(s_row + 4u * rows_per_iter);
+    __shared__ float s_lv[8];
+    const uint32_t col = Q.cbps / 16u, n_groups = Q.cbps / S;
+    if constexpr (!GROUPED)
+        for (uint32_t g = threadIdx.x; g < n_groups; g += blockDim.x) {
+            const uint32_t i0 = S * g, b = i0 / col;
+            s_g[g] = (uint16_t)(((i0 - b * col) << 4) | b);       // first unit of the group, bit position
+        }
+    if (threadIdx.x < (1u << S)) {
+        // rawofdm/src/lib/qam/raw_qam.cc:63-74: level of the axis index (first bit = MSB)
+        int pt = 0, flip = 1;
+        for (uint32_t t = 0; t < S; t++) {
+            const int bit = (int)((threadIdx.x >> (S - 1u - t)) & 1u) * 2 - 1;
+            pt = bit * flip + pt * 2;
+            flip *= -bit;
+        }
+        s_lv[threadIdx.x] = (float)pt * Q.scale;
+    }
+
+    const uint64_t n_rows = Q.n_values / Q.ncarriers;
+    const uint32_t cod_per_row = Q.cbps / NP * NC;                // coded bits behind one symbol
+    const uint32_t in_per_row = cod_per_row >> 1;                 // input bits behind one symbol
+    const uint32_t words_per_row = (cod_per_row + 63u) / 64u;     // 32-bit input words feeding one symbol
+    constexpr uint32_t PIN = NC == 4 ? 4 : 3, POUT = NC == 4 ? 3 : 2;
+    const uint32_t units = (cod_per_row + 32u * PIN - 1u) / (32u * PIN);
+    const RowWalk walk_in(threadIdx.x, blockDim.x, in_stride), walk_enc(threadIdx.x, blockDim.x, words_per_row),
+        walk_pun(threadIdx.x, blockDim.x, units),
+        walk_car(threadIdx.x, blockDim.x, GROUPED ? Q.ncarriers / 16u : Q.ncarriers);
+    for (uint64_t row0 = (uint64_t)blockIdx.x * rows_per_iter; row0 < n_rows; row0 += (uint64_t)gridDim.x * rows_per_iter) {
+        const uint32_t rows_here = n_rows - row0 < rows_per_iter ? (uint32_t)(n_rows - row0) : rows_per_iter;
+        __syncthreads();                                          // previous rows consumed (and tables written)
+        for (uint32_t rr = threadIdx.x; rr < rows_here; rr += blockDim.x) {
+            // where the row's input starts: frame, first staged byte (4 bytes ahead of the row's
+            // first input bit, may be negative), bit offset of that first input bit in the stage
+            const uint64_t row = row0 + rr, f = row / Q.nsymbols;
+            const uint32_t sym = (uint32_t)(row - f * Q.nsymbols);
+            const uint32_t n0 = sym * in_per_row;
+            const uint64_t base = f * Q.frame_bytes;
+            s_row[4u * rr + 0] = (uint32_t)base;
+            s_row[4u * rr + 1] = (uint32_t)(base >> 32);
+            s_row[4u * rr + 2] = (n0 >> 3);              // byte of the first input bit (stage starts 4 earlier)
+            s_row[4u * rr + 3] = 32u + (n0 & 7u);        // its bit offset in the stage
+        }
+        __syncthreads();
+        // ---- stage the frame bytes behind every row, zeros outside the frame (the padding byte
+        // of raw_qam.py:85 and the encoder's zero start state), as MSB-first words.  Frames lie back
+        // to back, so a word that straddles a frame boundary is loaded whole (only the ends of the
+        // buffer need a clamped address) and masked; a thread issues all its loads before it uses
+        // the first one.
+        for (RowWalk w = walk_in; w.r < rows_here;) {
+            constexpr int K = 4;
+            uint32_t le[K], lds_at[K], mask[K];
+            int shift[K];
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                lds_at[k] = 0xFFFFFFFFu;
+                if (w.r < rows_here) {
+                    const int64_t fb = (int64_t)s_row[4u * w.r + 2] - 4 + 4 * (int64_t)w.x;    // first of 4 frame bytes
+                    const int64_t g = (int64_t)(((uint64_t)s_row[4u * w.r + 1] << 32) | s_row[4u * w.r + 0]) + fb;
+                    int64_t gc = g < 0 ? 0 : g;
+                    gc = gc > (int64_t)Q.total_bytes - 4 ? (int64_t)Q.total_bytes - 4 : gc;
+                    __builtin_memcpy(&le[k], data + gc, 4);       // any alignment
+                    shift[k] = 8 * (int)(g - gc);                 // bytes the clamp moved the window by
+                    const int64_t lo = fb < 0 ? -fb : 0, hi = (int64_t)Q.frame_bytes - fb < 4 ? (int64_t)Q.frame_bytes - fb : 4;
+                    uint32_t m = 0;
+                    if (lo < hi) m = (0xFFFFFFFFu >> (8 * (int)lo)) & ~(hi < 4 ? 0xFFFFFFFFu >> (8 * (int)hi) : 0u);
+                    mask[k] = m;
+                    lds_at[k] = w.r * in_stride + w.x;
+                }
+                w.next();
+            }
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                if (lds_at[k] != 0xFFFFFFFFu) {
+                    const uint32_t be = __builtin_bswap32(le[k]);
+                    const int sh = shift[k];
+                    const uint32_t v = sh >= 32 || sh <= -32 ? 0u : sh > 0 ? be << sh : be >> (-sh);
+                    s_in[lds_at[k]] = v & mask[k];
+                }
+            }
+        }
+        __syncthreads();
+        // ---- rawofdm/src/lib/qam/raw_conv.cc:46-51, 32 input bits -> 64 coded bits per thread:
+        // polynomial 121 taps u[n], u[n-3..n-6]; 91 taps u[n], u[n-1], u[n-3], u[n-4], u[n-6]
+        for (RowWalk w = walk_enc; w.r < rows_here; w.next()) {
+            const uint32_t off = s_row[4u * w.r + 3] + 32u * w.x, q = off >> 5, sh = off & 31u;
+            const uint32_t *W = s_in + w.r * in_stride;
+            const uint32_t w0 = W[q - 1u], w1 = W[q], w2 = W[q + 1u];
+            const uint32_t prev = sh ? __funnelshift_l(w1, w0, sh) : w0, cur = sh ? __funnelshift_l(w2, w1, sh) : w1;
+            const uint32_t y1 = __funnelshift_r(cur, prev, 1), y3 = __funnelshift_r(cur, prev, 3);
+            const uint32_t y4 = __funnelshift_r(cur, prev, 4), y5 = __funnelshift_r(cur, prev, 5);
+            const uint32_t y6 = __funnelshift_r(cur, prev, 6);
+            const uint32_t aw = cur ^ y3 ^ y4 ^ y5 ^ y6, bw = cur ^ y1 ^ y3 ^ y4 ^ y6;
+            const uint64_t both = (spread_bits(aw) << 1) | spread_bits(bw);     // A before B, MSB first
+            s_cod[w.r * cod_stride + 2u * w.x] = (uint32_t)(both >> 32);
+            s_cod[w.r * cod_stride + 2u * w.x + 1u] = (uint32_t)both;
+        }
+        if constexpr (NP != NC) {
+            __syncthreads();
+            // ---- puncturing: 4 words -> 3 (keep 3 of 4) or 3 words -> 2 (keep 4 of 6) per thread
+            for (RowWalk w = walk_pun; w.r < rows_here; w.next()) {
+                const uint32_t *ci = s_cod + w.r * cod_stride + PIN * w.x;
+                uint32_t *po = s_pun + w.r * pun_stride + POUT * w.x;
+                if constexpr (NC == 4) {
+                    const uint32_t p0 = keep_3_of_4(ci[0]), p1 = keep_3_of_4(ci[1]), p2 = keep_3_of_4(ci[2]),
+                                   p3 = keep_3_of_4(ci[3]);
+                    po[0] = p0 | (p1 >> 24);
+                    po[1] = (p1 << 8) | (p2 >> 16);
+                    po[2] = (p2 << 16) | (p3 >> 8);
+                } else {
+                    const uint32_t w0 = ci[0], w1 = ci[1], w2 = ci[2];
+                    po[0] = (keep_4_of_6(w0 >> 8) << 16) | keep_4_of_6(((w0 & 0xFFu) << 16) | (w1 >> 16));
+                    po[1] = (keep_4_of_6(((w1 & 0xFFFFu) << 8) | (w2 >> 24)) << 16) | keep_4_of_6(w2 & 0xFFFFFFu);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- interleaver + QAM, one thread per carrier value
+        float2 *orow = out + row0 * Q.ncarriers;
+        if constexpr (GROUPED) {
+            const uint32_t G = Q.ncarriers / 16u;
+            for (RowWalk w = walk_car; w.r < rows_here; w.next()) {
+                const uint32_t *P = s_pun + w.r * p_stride;
+                uint32_t h[QB == 1 ? 1 : QB];                     // the units of the group, 16 bits each
+                if constexpr (QB == 1) {
+                    h[0] = (P[w.x >> 1] >> (16u * (1u - (w.x & 1u)))) & 0xFFFFu;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < QB / 2; i++) {
+                        const uint32_t v = P[(QB / 2) * w.x + i];
+                        h[2 * i] = v >> 16;
+                        h[2 * i + 1] = v & 0xFFFFu;
+                    }
+                }
+                emit_unit_group<QB, (int)S>(h, s_idx + w.r * Q.ncarriers + w.x, G, std::make_integer_sequence<int, 16>{});
+            }
+            __syncthreads();
+            // two values per thread: 16-byte stores, consecutive over the workgroup
+            const uint32_t n_val = rows_here * Q.ncarriers;       // even: ncarriers is a multiple of 16
+            for (uint32_t i = 2u * threadIdx.x; i < n_val; i += 2u * blockDim.x) {
+                const uint32_t v = *reinterpret_cast<const uint16_t *>(s_idx + i), v0 = v & 0xFFu, v1 = v >> 8;
+                *reinterpret_cast<float4 *>(orow + i) =
+                    make_float4(s_lv[v0 >> 3], QB == 1 ? 0.f : s_lv[v0 & 7u], s_lv[v1 >> 3], QB == 1 ? 0.f : s_lv[v1 & 7u]);
+            }
+        } else
+        for (RowWalk w = walk_car; w.r < rows_here; w.next()) {
+            // unit m of the MSB-first stream is the 16-bit element m ^ 1 of the little-endian words
+            const uint16_t *H = reinterpret_cast<const uint16_t *>(s_pun + w.r * p_stride);
+            float lv[2] = {0.f, 0.f};
+#pragma unroll
+            for (uint32_t a = 0; a < AXES; a++) {
+                const uint32_t e = s_g[w.x * AXES + a];
+                const uint32_t b = e & 15u, m0 = e >> 4;
+                uint32_t n = 0;                                   // the group's bits in stream order
+#pragma unroll
+                for (uint32_t t = 0; t < S; t++) n = (n << 1) | (((uint32_t)H[(m0 + t) ^ 1u] >> (15u - b)) & 1u);
+                // output bit t of the group is stream bit (t + b) % S: rotate left by b % S
+                uint32_t rot = 0;
+                if (S == 2) rot = b & 1u;
+                if (S == 3) rot = b - 3u * ((b * 11u) >> 5);      // b < 16
+                const uint32_t idx = S == 1 ? n : ((n << rot) | (n >> (S - rot))) & ((1u << S) - 1u);
+                lv[a] = s_lv[idx];
+            }
+            orow[(uint64_t)w.r * Q.ncarriers + w.x] = make_float2(lv[0], lv[1]);
         }
     }
 }
@@ -631,6 +875,7 @@ int ofdmtx_raw_qam_tx(ofdmtx_ctx *ctx, int qambits, int nc, int np, uint32_t nca
     const uint32_t s = qambits / 2 > 1 ? (uint32_t)qambits / 2 : 1u;
     if (Q.cbps % 16u != 0 || (Q.cbps / 16u) % s != 0) return OFDMTX_ESHAPE;
     Q.n_values = n_frames * (uint64_t)ncarriers * nsymbols;
+    Q.total_bytes = n_frames * (uint64_t)fb;
     if (Q.n_values == 0) return OFDMTX_OK;
     // raw_qam.cc:39-52,120-147: bits per axis and symbol power per constellation, float arithmetic as there
     const int numbits = qambits == 1 ? 1 : qambits / 2;
@@ -652,8 +897,40 @@ int ofdmtx_raw_qam_tx(ofdmtx_ctx *ctx, int qambits, int nc, int np, uint32_t nca
     const unsigned grid = (unsigned)(n_iters < cap ? n_iters : cap);
     hipStream_t st = (hipStream_t)stream;
     float2 *o2 = reinterpret_cast<float2 *>(d_out);
-#define LAUNCH_QAM(QB_, NC_, NP_) \
-    hipLaunchKernelGGL((k_raw_qam_tx<QB_, NC_, NP_>), dim3(grid), dim3(threads), lds, st, Q, d_bytes, o2, cod_words, rows_per_iter)
+    // table entries of raw_qam.py:19-28: the structured kernel (see k_raw_qam_tx_fast)
+    const uint32_t cod_stride = cod_words + 4u;                   // the puncturing pass reads whole units
+    const uint32_t cod_bits = Q.cbps / (uint32_t)np * (uint32_t)nc;
+    const uint32_t pun_stride = nc == np ? 0u : nc == 4 ? 3u * ((cod_bits + 127u) / 128u) : 2u * ((cod_bits + 95u) / 96u);
+    // staged input per row: 4 bytes ahead of the row's first input bit, the row's input bits, slack
+    // for a bit offset and the word read past the end
+    const uint32_t in_stride = (cod_bits / 2u + 31u) / 32u + 4u;
+    // rows per pass: the grouped form keeps one thread per 16 carriers busy, so it wants 16x the rows
+    const bool grouped = ncarriers % 16u == 0 && ((uintptr_t)d_out & 15u) == 0;      // it stores 16 bytes at a time
+    const uint32_t row_words = in_stride + cod_stride + pun_stride + 4u;
+    uint32_t rows_fast = grouped ? (4096u + ncarriers - 1u) / ncarriers : rows_per_iter;
+    // behind the rows: the group table (cbps / s entries), or in the grouped form one byte per value
+    const size_t tail_fixed = grouped ? 0 : (size_t)(Q.cbps / s) * sizeof(uint16_t);
+    const size_t row_bytes = row_words * sizeof(uint32_t) + (grouped ? ncarriers : 0u);
+    const uint32_t rows_fit = tail_fixed < 40000u ? (uint32_t)((48000u - tail_fixed) / row_bytes) : 0u;
+    if (rows_fast > rows_fit) rows_fast = rows_fit;
+    const size_t lds_fast = row_bytes * rows_fast + tail_fixed + 16u;
+    const bool fast_ok = rows_fast >= 1u && Q.total_bytes >= 4u && (Q.cbps / s) * sizeof(uint16_t) < 40000u && Q.cbps / 16u < 4096u;
+    const uint64_t iters_fast = fast_ok ? (n_rows + rows_fast - 1) / rows_fast : 1;
+    const unsigned grid_fast = (unsigned)(iters_fast < cap ? iters_fast : cap);
+#define LAUNCH_QAM(QB_, NC_, NP_)                                                                         \
+    do {                                                                                                  \
+        if (fast_ok && grouped)                                                                           \
+            hipLaunchKernelGGL((k_raw_qam_tx_fast<QB_, NC_, NP_, true>), dim3(grid_fast), dim3(threads),  \
+                               lds_fast, st, Q, d_bytes, o2, in_stride, cod_stride, pun_stride,           \
+                               rows_fast);                                                                \
+        else if (fast_ok)                                                                                 \
+            hipLaunchKernelGGL((k_raw_qam_tx_fast<QB_, NC_, NP_, false>), dim3(grid_fast), dim3(threads), \
+                               lds_fast, st, Q, d_bytes, o2, in_stride, cod_stride, pun_stride,           \
+                               rows_fast);                                                                \
+        else                                                                                              \
+            hipLaunchKernelGGL((k_raw_qam_tx<0, 0, 0>), dim3(grid), dim3(threads), lds, st, Q, d_bytes,   \
+                               o2, cod_words, rows_per_iter);                                             \
+    } while (0)
     const int key = qambits * 100 + nc * 10 + np;
     switch (key) {
     case 144: LAUNCH_QAM(1, 4, 4); break;
@@ -664,7 +941,10 @@ int ofdmtx_raw_qam_tx(ofdmtx_ctx *ctx, int qambits, int nc, int np, uint32_t nca
     case 464: LAUNCH_QAM(4, 6, 4); break;
     case 643: LAUNCH_QAM(6, 4, 3); break;
     case 664: LAUNCH_QAM(6, 6, 4); break;
-    default: LAUNCH_QAM(0, 0, 0); break;
+    default:
+        hipLaunchKernelGGL((k_raw_qam_tx<0, 0, 0>), dim3(grid), dim3(threads), lds, st, Q, d_bytes, o2, cod_words,
+                           rows_per_iter);
+        break;
     }
 #undef LAUNCH_QAM
     HIPCHK(hipGetLastError());

@@ -282,6 +282,47 @@ def test_gpu_qam_tx_bit_exact(txctx, bitrate, ncarriers, nsymbols):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("bitrate", range(3, 9))
+@pytest.mark.parametrize("ncarriers,nsymbols,n_frames", [(40, 16, 5), (24, 16, 1), (8, 32, 9), (56, 8, 300)])
+def test_gpu_qam_tx_carrier_counts_off_the_16_grid(txctx, bitrate, ncarriers, nsymbols, n_frames):
+    """Carrier counts that are not multiples of 16 take the per-carrier form of the kernel (a
+    carrier's bits then need not share one bit position of the interleaver's 16 columns); many
+    frames make several passes per workgroup; one frame has both buffer ends in its first words."""
+    import torch
+    from ofdm_amd import raw
+    qambits, punc = ro.BITRATES[bitrate]
+    rng = np.random.default_rng(1000 * bitrate + ncarriers)
+    tx = raw.qam_tx(bitrate, ncarriers, nsymbols, ctx=txctx)
+    data = rng.integers(0, 256, n_frames * tx.framebytes, dtype=np.uint8)
+    got = tx.modulate(torch.from_numpy(data)).cpu().numpy()
+    want, _ = ro.qam_tx(bitrate, ncarriers, nsymbols, data.tobytes())
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+
+
+@pytest.mark.gpu
+def test_gpu_qam_tx_many_frames(txctx):
+    """Enough frames that every workgroup makes several passes; odd frame sizes (words that
+    straddle frame boundaries).  Frames are independent, so the oracle runs on slices of them:
+    the first, the last and some in the middle."""
+    import torch
+    from ofdm_amd import raw
+    rng = np.random.default_rng(5)
+    for bitrate, ncarriers, nsymbols, n_frames in ((8, 192, 16, 6000), (7, 48, 16, 12000), (2, 208, 4, 20000),
+                                                   (5, 768, 2, 9000), (6, 40, 16, 9000)):
+        tx = raw.qam_tx(bitrate, ncarriers, nsymbols, ctx=txctx)
+        fb, per_frame = tx.framebytes, ncarriers * nsymbols
+        data = rng.integers(0, 256, n_frames * fb, dtype=np.uint8)
+        got = tx.modulate(torch.from_numpy(data)).cpu().numpy()
+        assert got.size == n_frames * per_frame
+        for f0, f1 in ((0, 6), (n_frames // 2 - 3, n_frames // 2 + 3), (n_frames - 6, n_frames), (1234, 1237)):
+            want, _ = ro.qam_tx(bitrate, ncarriers, nsymbols, data[f0 * fb:f1 * fb].tobytes())
+            assert np.array_equal(got[f0 * per_frame:f1 * per_frame].view(np.uint64), want.view(np.uint64)), \
+                (bitrate, ncarriers, f0)
+        # every value is a constellation point of the right power on average (raw_qam.cc:39-52)
+        assert abs(float(np.mean(np.abs(got) ** 2)) - 1.0) < 0.02
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("bitrate,nfft", [(1, 64), (4, 256), (6, 256), (7, 1024), (8, 1024)])
 def test_gpu_bytes_to_iq_and_back(txctx, bitrate, nfft):
     """Bytes -> qam_tx -> ofdm_mod on the GPU; an ideal receiver (FFT, de-map, soft decisions,

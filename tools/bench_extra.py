@@ -49,9 +49,12 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--ragged-packets", type=int, default=400_000)
     ap.add_argument("--raw-symbols", type=int, default=1 << 20)
+    ap.add_argument("--only", choices=["qam"], default=None, help="run one section only")
     a = ap.parse_args()
     ctx = TxContext(0)
     dev = ctx.device
+    if a.only == "qam":
+        return bench_qam_tx(ctx, a.steps)
 
     # mixed-rate ragged batch: all eight rates, payload lengths 1..2304 bytes
     rng = np.random.default_rng(3)
