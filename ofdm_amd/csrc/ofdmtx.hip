@@ -356,30 +356,51 @@ __device__ __forceinline__ void scramble_packet(const Pkt &k, const RegimeInfo &
     // ---- 1. MPDU in natural byte order (pu:28-36,100), Dw[-2], Dw[-1] and the tail zero
     uint32_t *Dw = A + 2;
     {
-        const uintptr_t ad = reinterpret_cast<uintptr_t>(payloads + k.pay_off);
-        const uint32_t a = (uint32_t)(ad & 3u);
-        const uint32_t *q = reinterpret_cast<const uint32_t *>(ad - a);
-        for (uint32_t i = lane; i < n_words + 3u; i += 64) {
-            const int idx = (int)i - 2;
+        // A[0], A[1] = 0; A[2..7] = MAC header; A[8 + j] = payload dword j; zeros up to A[n_words + 2]
+        if (lane < 8) {
             uint32_t v = 0;
-            if (idx >= 6 && (uint32_t)idx < n_dw) {
-                const uint32_t j = (uint32_t)idx - 6u;
-                const uint32_t nb = k.pay_len - 4u * j < 4u ? k.pay_len - 4u * j : 4u;
-                const uint32_t lo = q[j];
-                const uint32_t hi = (a + nb > 4u) ? q[j + 1] : 0u;
-                v = (uint32_t)((((uint64_t)hi << 32) | lo) >> (8u * a));
-                if (nb < 4u) v &= (1u << (8u * nb)) - 1u;
-            } else if (idx >= 0 && idx < 6) {
-                switch (idx) {
-                case 0: v = 0x00000008u | ((k.txtime >> 8) & 0xFFu) << 16 | (k.txtime & 0xFFu) << 24; break;  // pu:91
-                case 1: v = 0xcd086000u; break;
-                case 2: v = 0x2000a637u; break;
-                case 3: v = 0xf13c01d6u; break;
-                case 4: v = 0xad086000u; break;
-                default: v = 0x0000af3bu; break;
+            v = lane == 2 ? (0x00000008u | ((k.txtime >> 8) & 0xFFu) << 16 | (k.txtime & 0xFFu) << 24) : v;   // pu:91
+            v = lane == 3 ? 0xcd086000u : v;
+            v = lane == 4 ? 0x2000a637u : v;
+            v = lane == 5 ? 0xf13c01d6u : v;
+            v = lane == 6 ? 0xad086000u : v;
+            v = lane == 7 ? 0x0000af3bu : v;
+            A[lane] = v;
+        }
+        // The payload may start at any byte: aligned dwords q[j], q[j + 1] are funnelled together.
+        // All loads of a round are issued before the first is used (a loop of load -> LDS write
+        // would wait for each load in turn: one HBM round trip per 64 words).
+        const uint8_t *pp = payloads + k.pay_off;
+        const uint32_t al = (uint32_t)(reinterpret_cast<uintptr_t>(pp) & 3u);
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(pp - al);
+        const uint32_t n_pw = n_dw - 6u;                                     // payload dwords, the last may be partial
+        const uint32_t total = n_words + 3u - 8u;                            // words behind the header to write
+        constexpr int K = 8;
+        for (uint32_t j0 = (uint32_t)lane; j0 < total; j0 += 64u * K) {
+            uint32_t lo[K], hi[K];
+#pragma unroll
+            for (int kk = 0; kk < K; kk++) {
+                const uint32_t j = j0 + 64u * kk;
+                lo[kk] = j < n_pw ? q[j] : 0u;
+            }
+            if (al) {
+#pragma unroll
+                for (int kk = 0; kk < K; kk++) {
+                    const uint32_t j = j0 + 64u * kk;
+                    const uint32_t nb = k.pay_len - 4u * j < 4u ? k.pay_len - 4u * j : 4u;
+                    hi[kk] = (j < n_pw && al + nb > 4u) ? q[j + 1] : 0u;
                 }
             }
-            A[i] = v;
+#pragma unroll
+            for (int kk = 0; kk < K; kk++) {
+                const uint32_t j = j0 + 64u * kk;
+                if (j < total) {
+                    uint32_t v = al ? (uint32_t)((((uint64_t)hi[kk] << 32) | lo[kk]) >> (8u * al)) : lo[kk];
+                    const uint32_t nb = k.pay_len - 4u * j;                  // bytes left from this word on
+                    if (j < n_pw && nb < 4u) v &= (1u << (8u * nb)) - 1u;
+                    A[8u + j] = j < n_pw ? v : 0u;
+                }
+            }
         }
     }
     wave_sync();
@@ -947,7 +968,16 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ in, float2 *__restri
             const uint32_t msg_len = 6u + k.n_sym * (uint32_t)ri.n_cbps / 8u;
             const uint32_t n_mw = (msg_len + 3u) / 4u;
             const uint32_t *mp = reinterpret_cast<const uint32_t *>(in + k.msg_off);
-            for (uint32_t w = lane; w < n_mw + 2u; w += 64) U[w] = w < n_mw ? __builtin_bswap32(mp[w]) : 0u;
+            // (all loads of a round first: a loop of load -> LDS write waits for every load in turn)
+            constexpr int K = 8;
+            for (uint32_t w0 = (uint32_t)lane; w0 < n_mw + 2u; w0 += 64u * K) {
+                uint32_t mv[K];
+#pragma unroll
+                for (int kk = 0; kk < K; kk++) mv[kk] = w0 + 64u * kk < n_mw ? mp[w0 + 64u * kk] : 0u;
+#pragma unroll
+                for (int kk = 0; kk < K; kk++)
+                    if (w0 + 64u * kk < n_mw + 2u) U[w0 + 64u * kk] = __builtin_bswap32(mv[kk]);
+            }
             wave_sync();
         } else {
             scramble_packet(k, ri, T, in, A, U, s_crc, s_scr, lane, nullptr, nullptr);
