@@ -108,14 +108,17 @@ constexpr int RAW_WAVES = 4;
 // 0 .. n_groups-1) or the copy of one frame's preamble rows (the items after those).
 //   bin k = l + L m of the (DC-centred) input:  x[M q + p] = sum_l W_L^{l q} W_N^{l p} sum_m X[l + L m] W_M^{m p}
 // step 1: lane l < L transforms its M bins in registers, applies W_N^{l p} / sqrt(N) and writes
-// to LDS; step 2: lane p < M reads the L partial results and transforms them; samples M q + p of
-// one q are contiguous over the lanes p, so the rows are stored straight from registers.
+// to LDS; step 2: lane p < M reads the L partial results and transforms them, and puts its
+// samples M q + p, cyclic prefix included, back into the symbol's LDS area as one output row;
+// step 3: the wave stores the rows with 16 bytes per lane, consecutive over the lanes.
 template <int L, int M>
 __global__ void __launch_bounds__(64 * RAW_WAVES)
 k_raw_modulate(RawParams R, const float2 *__restrict__ data, float2 *__restrict__ mapped, float2 *__restrict__ iq)
 {
     constexpr int N = L * M, S = L > M ? L : M, SPW = 64 / S;
-    constexpr int TS = M * (L + 1);                       // float2 per symbol in the transposition area (rows padded by 1)
+    constexpr int TT = M * (L + 1);                       // float2 per symbol in the transposition area (rows padded by 1)
+    // the area also stages the symbol's output row (N + cp <= 2 N samples), on a 16-byte boundary
+    const int TS = ((TT > (int)(R.n + R.cp) ? TT : (int)(R.n + R.cp)) + 1) & ~1;
     extern __shared__ __align__(16) unsigned char s_raw[];
     v2f *s_tw = reinterpret_cast<v2f *>(s_raw);                            // N
     v2f *s_t = s_tw + N;                                                   // RAW_WAVES * SPW * TS
@@ -192,21 +195,36 @@ k_raw_modulate(RawParams R, const float2 *__restrict__ data, float2 *__restrict_
 
         // ---- step 2: L-point transforms, cyclic prefix (gr-digital ofdm_cyclic_prefixer,
         // rawofdm/src/python/raw_ofdm_mod.py:47) and stores
+        v2f y[L];
         if (active && t < M) {
-            v2f y[L];
 #pragma unroll
             for (int l = 0; l < L; l++) y[bit_reverse(l, L)] = T[t * (L + 1) + l];
             idft_reg<L>(y);
-            if (row != ROW_DROPPED) {
-                float2 *o = iq + (size_t)row * row_len;
-                const uint32_t tail = R.n - R.cp;             // samples >= tail are repeated in front
+        }
+        wave_sync();                                              // the partial results are consumed
+        if (active && t < M && row != ROW_DROPPED) {
+            const uint32_t tail = R.n - R.cp;                     // samples >= tail are repeated in front
 #pragma unroll
-                for (int q = 0; q < L; q++) {
-                    const uint32_t n = (uint32_t)(M * q + t);
-                    const float2 v = make_float2(y[q].x, y[q].y);
-                    o[R.cp + n] = v;
-                    if (n >= tail) o[n - tail] = v;
-                }
+            for (int q = 0; q < L; q++) {
+                const uint32_t n = (uint32_t)(M * q + t);
+                T[R.cp + n] = y[q];
+                if (n >= tail) T[n - tail] = y[q];
+            }
+        }
+        wave_sync();
+        // ---- step 3: rows to memory (a row starts on a 16-byte boundary when row_len is even)
+#pragma unroll
+        for (int sl = 0; sl < SPW; sl++) {
+            const uint32_t row_s = __shfl(row, sl * S);           // the row of slot sl
+            if (row_s == ROW_DROPPED) continue;
+            const v2f *Ts = s_t + (wave * SPW + sl) * TS;
+            float2 *o = iq + (size_t)row_s * row_len;
+            if ((row_len & 1u) == 0u) {
+                const float4 *src4 = reinterpret_cast<const float4 *>(Ts);
+                float4 *dst4 = reinterpret_cast<float4 *>(o);
+                for (uint32_t i = lane; i < row_len / 2; i += 64) dst4[i] = src4[i];
+            } else {
+                for (uint32_t i = lane; i < row_len; i += 64) o[i] = make_float2(Ts[i].x, Ts[i].y);
             }
         }
         wave_sync();
@@ -214,9 +232,10 @@ k_raw_modulate(RawParams R, const float2 *__restrict__ data, float2 *__restrict_
 }
 
 template <int L, int M>
-size_t raw_lds_bytes()
+size_t raw_lds_bytes(uint32_t row_len)
 {
-    constexpr int N = L * M, S = L > M ? L : M, SPW = 64 / S, TS = M * (L + 1);
+    constexpr int N = L * M, S = L > M ? L : M, SPW = 64 / S, TT = M * (L + 1);
+    const int TS = ((TT > (int)row_len ? TT : (int)row_len) + 1) & ~1;
     return (size_t)N * sizeof(float2) + (size_t)RAW_WAVES * SPW * TS * sizeof(float2) + (size_t)N * sizeof(int16_t);
 }
 
@@ -225,7 +244,7 @@ int launch_raw(const ofdmtx_ctx *ctx, const RawParams &rp, const float2 *data, f
                hipStream_t st)
 {
     constexpr int S = L > M ? L : M, SPW = 64 / S;
-    const size_t lds = raw_lds_bytes<L, M>();
+    const size_t lds = raw_lds_bytes<L, M>(rp.n + rp.cp);
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_raw_modulate<L, M>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint64_t items = ((uint64_t)rp.n_sym + SPW - 1) / SPW + rp.n_frames;
