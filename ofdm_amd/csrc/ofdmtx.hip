@@ -93,7 +93,8 @@ struct PlanParams {
     // ragged batches
     const PktRec *recs;
     const uint32_t *row_start;    // n_pkts + 1
-    uint32_t *next_pkt;           // work counter of the fused kernel (zeroed before each launch)
+    uint32_t *next_pkt;           // work counters, zeroed before each launch: [0] k_tx, [1] k_encode_bits
+    uint32_t grab_tx, grab_enc;   // packets per draw from the counters
     uint32_t total_rows;
     uint32_t flags;
     float amp;
@@ -734,7 +735,22 @@ k_encode_bits(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads,
     uint32_t *A = s_a[wave];
     uint32_t *U = s_u[wave];
 
-    for (uint32_t p = blockIdx.x * ENC_WAVES + wave; p < P.n_pkts; p += gridDim.x * ENC_WAVES) {
+    // ragged plans: packets are drawn from the plan's second work counter (their cost follows
+    // their length); uniform plans use a fixed stride
+    uint32_t p_end = 0;
+    auto next_packet = [&](uint32_t prev, bool first) -> uint32_t {
+        if constexpr (UNIFORM) {
+            return first ? blockIdx.x * ENC_WAVES + wave : prev + gridDim.x * ENC_WAVES;
+        } else {
+            if (!first && prev + 1u < p_end) return prev + 1u;
+            uint32_t v = 0;
+            if (lane == 0) v = atomicAdd(P.next_pkt + 1, P.grab_enc);
+            v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+            p_end = v + P.grab_enc;
+            return v;
+        }
+    };
+    for (uint32_t p = next_packet(0, true); p < P.n_pkts; p = next_packet(p, false)) {
         const Pkt k = load_pkt<UNIFORM>(P, p);
         const RegimeInfo ri = regime_info(REGIME ? REGIME : (int)k.regime);
         const uint32_t msg_len = 6u + k.n_sym * ri.n_cbps / 8u;
@@ -946,13 +962,19 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ in, float2 *__restri
     // Uniform plans: packets cost the same, a fixed stride balances the waves.  Ragged plans: a
     // packet's cost follows its symbol count (1 .. 1366 rows), so each wave draws its next packet
     // from a counter instead (lane 0 asks, the wave reads the answer from lane 0).
+    // A draw takes P.grab_tx consecutive packets: one address sustains only ~10^8 atomics per
+    // second, which a batch of short packets would exceed at one draw per packet.
+    uint32_t p_end = 0;
     auto next_packet = [&](uint32_t prev, bool first) -> uint32_t {
         if constexpr (UNIFORM) {
             return first ? blockIdx.x * n_wv + wave : prev + gridDim.x * n_wv;
         } else {
+            if (!first && prev + 1u < p_end) return prev + 1u;
             uint32_t v = 0;
-            if (lane == 0) v = atomicAdd(P.next_pkt, 1u);
-            return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+            if (lane == 0) v = atomicAdd(P.next_pkt, P.grab_tx);
+            v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+            p_end = v + P.grab_tx;
+            return v;
         }
     };
     for (uint32_t p = next_packet(0, true); p < P.n_pkts; p = next_packet(p, false)) {
@@ -1483,6 +1505,13 @@ int ofdmtx_plan_ragged(ofdmtx_ctx *ctx, uint64_t n_pkts, const uint8_t *regimes,
     pp.recs = pl->d_recs;
     pp.row_start = pl->d_row_start;
     pp.next_pkt = pl->d_row_start + counter_at / sizeof(uint32_t);
+    // packets per draw: about 128 output rows (80 KB of samples) for k_tx, eight times as many
+    // packets for the much cheaper k_encode_bits; 1 for batches of ordinary packets
+    {
+        const uint64_t avg_rows = n_pkts ? (rows + n_pkts - 1) / n_pkts : 1;
+        pp.grab_tx = (uint32_t)(avg_rows >= 128 ? 1 : 128 / (avg_rows ? avg_rows : 1));
+        pp.grab_enc = 8u * pp.grab_tx;
+    }
     *out = pl;
     return OFDMTX_OK;
 }
@@ -1563,6 +1592,7 @@ int ofdmtx_encode_bits(ofdmtx_ctx *ctx, const ofdmtx_plan *pl, const uint8_t *d_
     hipLaunchKernelGGL((k_encode_bits<U_, R_>), dim3(grid), dim3(64 * ENC_WAVES), 0, st, pp, tab,    \
                        d_payloads, d_plcp, d_scrambled, d_coded, d_interleaved)
     if (!pp.uniform) {
+        HIPCHK(hipMemsetAsync(pp.next_pkt + 1, 0, sizeof(uint32_t), st));
         LAUNCH_ENC(false, 0);
     } else {
         switch (pp.regime) {

@@ -270,6 +270,19 @@ def test_ragged_plan_reuse(txctx, c_oracle):
         assert rel_l2_rows(iq[a:a + len(want)], want).max() <= REL_L2_TOL
 
 
+def test_ragged_short_packets(txctx, c_oracle):
+    """Batches of very short packets: the waves then draw several packets per visit to the work
+    counter (the last draw is a partial one).  Every packet against the oracle."""
+    rng = np.random.default_rng(24)
+    for n in (1, 7, 5003):
+        regs = rng.integers(1, 9, n).astype(np.uint8)
+        lens = rng.integers(0, 21, n).astype(np.uint32)
+        buf = rng.integers(0, 256, int(lens.sum()), dtype=np.uint8)
+        flags = _lib.F_PREAMBLE | _lib.F_ZEROGAP
+        plan = txctx.plan_ragged(regs, lens, pilot_start=77, flags=flags, amp=0.3)
+        check_plan(plan, buf, lens.tolist(), regs.tolist(), c_oracle, flags, 0.3)
+
+
 def test_custom_constellation(txctx, c_oracle):
     """The `constellation` argument of ftw.ofdm_mapper (ftw/ftw.i:157-163): replaced points show up
     in the mapper tap and in the IQ; the SIGNAL symbol keeps its fixed BPSK."""

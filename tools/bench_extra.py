@@ -74,6 +74,20 @@ def main():
          plan.n_samples, {"packets": n, "k_encode_bits_ms": ms_e})
     del iq, msg, payloads, plan
 
+    # short packets (ACK-sized .. 100 bytes), all rates: many packets per output byte
+    n = 2_000_000
+    regimes = rng.integers(1, 9, n).astype(np.uint8)
+    lens = rng.integers(0, 101, n).astype(np.uint32)
+    payloads = torch.randint(0, 256, (int(lens.sum()),), dtype=torch.uint8, device=dev)
+    plan = ctx.plan_ragged(regimes, lens)
+    iq = plan.alloc_iq()
+    ms = timed(lambda: plan.tx(payloads, out=iq), a.steps)
+    msg = plan.alloc_msg()
+    ms_e = timed(lambda: plan.encode_bits(payloads, out=msg), a.steps)
+    line("short packets (0..100 bytes), mixed rates, payload -> IQ (fused kernel)", ms, int(lens.sum()) + plan.n_samples * 8,
+         plan.n_samples, {"packets": n, "k_encode_bits_ms": ms_e})
+    del iq, msg, payloads, plan
+
     # uniform batches of the other rates, fused kernel
     for regime in (1, 3, 5, 7):
         npk = 200_000 if regime == 1 else 500_000
