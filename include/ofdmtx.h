@@ -205,6 +205,32 @@ int ofdmtx_scale_cc(ofdmtx_ctx *ctx, const float *d_in, uint64_t n, float k_re, 
 int ofdmtx_repeat(ofdmtx_ctx *ctx, const float *d_in, uint64_t period, uint64_t n_out, float *d_out,
                   void *stream);
 
+/* ---- loop-back verifier ------------------------------------------------------------------
+ * A receiver for the noiseless frames of ofdmtx_tx / ofdmtx_modulate, written from IEEE
+ * 802.11-2007 clause 17 (the reference has no receiver for this chain; its rawofdm tests check
+ * a loop-back, rawofdm/src/python/qa_ofdm.py:40-67).  Frame geometry comes from the plan; rate
+ * and length are also read from the decoded SIGNAL field and compared.
+ *
+ * ofdmtx_rx_demod: d_iq (the plan's n_samples complex64) -> d_coded: per packet the hard
+ *   decisions as coded bits in transmit order, at the plan's message offsets (msg_bytes bytes:
+ *   the layout and, for a clean loop-back, the content of the d_coded tap of
+ *   ofdmtx_encode_bits); d_status[n_pkts] is SET to the OFDMTX_RX_PILOTS / _NULLS bits.
+ * ofdmtx_rx_decode: d_coded -> d_payloads (payload bytes at the plan's payload offsets,
+ *   payload_bytes bytes); ORs the remaining bits into d_status (zero it first if
+ *   ofdmtx_rx_demod did not write it). */
+#define OFDMTX_RX_PILOTS 1u   /* a pilot carrier is not what the plan's pilot mode prescribes   */
+#define OFDMTX_RX_NULLS 2u    /* energy on DC or a guard carrier                                */
+#define OFDMTX_RX_SIGNAL 4u   /* SIGNAL field: RATE differs from the plan, reserved bit, parity or tail */
+#define OFDMTX_RX_LENGTH 8u   /* SIGNAL field: LENGTH differs from 24 + payload + 4             */
+#define OFDMTX_RX_SERVICE 16u /* SERVICE bits not zero after descrambling                       */
+#define OFDMTX_RX_TAIL 32u    /* the six tail bits are not zero                                 */
+#define OFDMTX_RX_FCS 64u     /* CRC-32 of the MPDU differs from the received FCS               */
+#define OFDMTX_RX_CODE 128u   /* a coded bit contradicts the bits decoded before it             */
+int ofdmtx_rx_demod(ofdmtx_ctx *ctx, const ofdmtx_plan *plan, const float *d_iq, uint8_t *d_coded,
+                    uint32_t *d_status, void *stream);
+int ofdmtx_rx_decode(ofdmtx_ctx *ctx, const ofdmtx_plan *plan, const uint8_t *d_coded,
+                     uint8_t *d_payloads, uint32_t *d_status, void *stream);
+
 /* ---- variable-size modulator (rawofdm) --------------------------------------------------
  * Stands in for raw.ofdm_mapper (rawofdm/src/lib/ofdm/raw_ofdm.i:18-20,
  * rawofdm/src/lib/ofdm/raw_ofdm_mapper.cc:22-80) and the GNU Radio blocks wired behind it in

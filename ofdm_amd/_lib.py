@@ -14,6 +14,8 @@ OK = 0
 EINVAL, EREGIME, ELENGTH, EHIP, ENOMEM, ESHAPE, ETOOBIG = -1, -2, -3, -4, -5, -6, -7
 F_PREAMBLE, F_ZEROGAP, F_SWAPIQ, F_PNC_A, F_PNC_B = 1, 2, 4, 8, 16
 PILOT_REF_STREAM, PILOT_PER_PACKET, PILOT_PNC_A, PILOT_PNC_B, PILOT_PNC_ALL = 0, 1, 2, 3, 4
+# status bits of the loop-back verifier (ofdmtx_rx_demod / ofdmtx_rx_decode)
+RX_PILOTS, RX_NULLS, RX_SIGNAL, RX_LENGTH, RX_SERVICE, RX_TAIL, RX_FCS, RX_CODE = 1, 2, 4, 8, 16, 32, 64, 128
 
 
 class OfdmTxError(RuntimeError):
@@ -62,6 +64,8 @@ PROTOTYPES = {
     "ofdmtx_conv_encode": (C.c_int, [_VP, _VP, C.c_uint32, C.c_int, C.c_uint32, _VP, _VP]),
     "ofdmtx_interleave": (C.c_int, [_VP, _VP, C.c_uint32, C.c_int, _VP, _VP]),
     "ofdmtx_scale_cc": (C.c_int, [_VP, _VP, C.c_uint64, C.c_float, C.c_float, _VP, _VP]),
+    "ofdmtx_rx_demod": (C.c_int, [_VP] * 6),
+    "ofdmtx_rx_decode": (C.c_int, [_VP] * 6),
     "ofdmtx_repeat": (C.c_int, [_VP, _VP, C.c_uint64, C.c_uint64, _VP, _VP]),
     "ofdmtx_raw_plan_frames": (C.c_int, [_VP, C.c_uint32, C.c_uint32, _VP, _VP, C.c_uint32, C.c_uint64,
                                          C.c_uint32, C.POINTER(_VP)]),

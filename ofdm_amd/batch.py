@@ -173,7 +173,36 @@ class TxPlan:
         """payload -> IQ for the whole batch."""
         self._check_payloads(payloads)
         iq = out if out is not None else self.alloc_iq()
-        work = work if work is not None else self.alloc_msg()
+        # (the fused kernel keeps the mapper messages in LDS: no work buffer is needed)
         _lib.check(self._lib.ofdmtx_tx(self.ctx._h, self._h, _ptr(payloads), _ptr(work), _ptr(iq),
                                        _stream(self.ctx.device)))
         return iq
+
+    # ---- loop-back verifier
+    def rx_demod(self, iq, out=None):
+        """IQ stream of this plan's geometry -> (hard coded bits in the layout of the `coded` tap,
+        per-packet status words)."""
+        if iq.dtype != torch.complex64 or iq.device != self.ctx.device or iq.numel() < self.n_samples:
+            raise ValueError("iq must be complex64 on %s with >= %d samples" % (self.ctx.device, self.n_samples))
+        coded = out if out is not None else self.alloc_msg()
+        status = torch.zeros(max(self.n_pkts, 1), dtype=torch.int32, device=self.ctx.device)
+        _lib.check(self._lib.ofdmtx_rx_demod(self.ctx._h, self._h, _ptr(iq), _ptr(coded), _ptr(status),
+                                             _stream(self.ctx.device)))
+        return coded, status[:self.n_pkts]
+
+    def rx_decode(self, coded, status=None):
+        """Coded bits -> (payload bytes at the plan's payload offsets, status words; bits RX_*)."""
+        if coded.dtype != torch.uint8 or coded.device != self.ctx.device or coded.numel() < self.msg_bytes:
+            raise ValueError("coded buffer must be uint8 on %s with >= %d bytes" % (self.ctx.device, self.msg_bytes))
+        if status is None:
+            status = torch.zeros(max(self.n_pkts, 1), dtype=torch.int32, device=self.ctx.device)[:self.n_pkts]
+        payloads = torch.zeros(max(self.payload_bytes, 1), dtype=torch.uint8, device=self.ctx.device)
+        _lib.check(self._lib.ofdmtx_rx_decode(self.ctx._h, self._h, _ptr(coded), _ptr(payloads), _ptr(status),
+                                              _stream(self.ctx.device)))
+        return payloads[:self.payload_bytes], status
+
+    def loopback(self, iq):
+        """Receive what tx() / modulate() produced: (payload bytes, status words -- all zero and
+        equal to the transmitted payloads for a clean loop-back)."""
+        coded, status = self.rx_demod(iq)
+        return self.rx_decode(coded, status)

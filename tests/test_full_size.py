@@ -63,6 +63,12 @@ def test_config2_one_million_packets(txctx, c_oracle):
     assert torch.equal(rows[127 * 5 + 3].view(torch.int64), rows[3].view(torch.int64))
     assert torch.equal(rows[999_000].view(torch.int64), rows[999_000 - 127 * 40].view(torch.int64))
     assert not torch.equal(rows[4].view(torch.int64), rows[3].view(torch.int64))
+    # end to end: the standards-based receiver returns every one of the 10^6 payloads, every FCS
+    # checks, every redundant coded bit agrees, every pilot and null carrier is in place
+    got, status = plan.loopback(iq)
+    assert int(status.abs().max()) == 0
+    assert equal_chunked(got[:n * ln - (n * ln) % 4], payloads[:n * ln - (n * ln) % 4])
+    del got, status
     # random packets against the oracle
     lay_msg = 2064
     rng = np.random.default_rng(7)
@@ -96,6 +102,11 @@ def test_config3_mixed_rate_ragged(txctx, c_oracle):
     iq2 = plan.modulate(taps["interleaved"])
     torch.cuda.synchronize()
     assert equal_chunked(iq, iq2)
+    del iq2
+    got, status = plan.loopback(iq)             # every packet decodes to its payload
+    assert int(status.abs().max()) == 0
+    assert torch.equal(got, payloads)
+    del got, status
     lay = plan.layout()
     pay_off = np.concatenate([[0], np.cumsum(lens.astype(np.int64))])
     for i in [0, n - 1] + list(rng.integers(0, n, 40)):

@@ -70,6 +70,9 @@ def main():
     msg = plan.alloc_msg()
     ms_e = timed(lambda: plan.encode_bits(payloads, out=msg), a.steps)
     ms_m = timed(lambda: plan.modulate(msg, out=iq), a.steps)
+    ms_rx = timed(lambda: plan.loopback(iq), max(1, a.steps // 2))
+    print(json.dumps({"workload": "loop-back verifier on the mixed-rate ragged batch (demod + decode)", "total_ms": ms_rx,
+                      "Msamples_per_s": plan.n_samples / (ms_rx * 1e-3) / 1e6, "packets": n}), flush=True)
     line("mixed-rate ragged batch, mapper messages -> IQ (k_tx, message input)", ms_m, plan.msg_bytes + plan.n_samples * 8,
          plan.n_samples, {"packets": n, "k_encode_bits_ms": ms_e})
     del iq, msg, payloads, plan
