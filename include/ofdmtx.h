@@ -135,9 +135,10 @@ int ofdmtx_plan_uniform(ofdmtx_ctx *ctx, uint64_t n_pkts, int regime, uint32_t p
                         uint32_t pilot_start, unsigned flags, float amp, ofdmtx_plan **out);
 /* Ragged / mixed-rate batch.  regimes[n], payload_len[n], payload_off[n] (byte offset of each
  * payload in the payload buffer; NULL = densely packed in order) are host arrays.
- * A ragged plan owns a device-side work counter that ofdmtx_tx / ofdmtx_modulate reset on their
- * stream before the launch: the same ragged plan must not be in flight on two streams at once
- * (one plan per stream; uniform plans have no such limit). */
+ * A ragged plan owns device-side work counters from which the waves of ofdmtx_tx /
+ * ofdmtx_modulate / ofdmtx_encode_bits draw packets (each kernel leaves them at zero when it
+ * ends): the same ragged plan must not run in two launches at once -- one plan per stream;
+ * uniform plans have no such limit. */
 int ofdmtx_plan_ragged(ofdmtx_ctx *ctx, uint64_t n_pkts, const uint8_t *regimes,
                        const uint32_t *payload_len, const uint64_t *payload_off,
                        double symbol_time, int pilot_mode, uint32_t pilot_start, unsigned flags,

@@ -71,7 +71,8 @@ struct PlanParams {
     // ragged batches
     const PktRec *recs;
     const uint32_t *row_start;    // n_pkts + 1
-    uint32_t *next_pkt;           // work counters, zeroed before each launch: [0] k_tx, [1] k_encode_bits
+    uint32_t *next_pkt;           // work counters (next packet, waves done): [0], [1] k_tx; [2], [3] k_encode_bits;
+                                  // zero between launches (the kernels restore them)
     uint32_t grab_tx, grab_enc;   // packets per draw from the counters
     uint32_t total_rows;
     uint32_t flags;

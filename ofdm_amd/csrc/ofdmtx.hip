@@ -38,6 +38,22 @@ namespace {
 
 using namespace ofdmtx_detail;
 
+// Work counters of a ragged plan: ctr[0] is the next packet to draw, ctr[1] counts the waves
+// that have left the packet loop.  The last wave out puts both back to zero, so a launch finds
+// the counters as the plan's creation left them and nothing has to be cleared between launches
+// (every wave draws at least once and draws no more after it has signed off; the reset is
+// ordered behind all draws by the sign-off atomics).
+__device__ __forceinline__ void sign_off(uint32_t *ctr, uint32_t n_waves, int lane)
+{
+    if (lane == 0) {
+        __threadfence();
+        if (atomicAdd(ctr + 1, 1u) == n_waves - 1u) {
+            atomicExch(ctr, 0u);
+            atomicExch(ctr + 1, 0u);
+        }
+    }
+}
+
 // ======================================================================================
 // Bit-level kernel
 // ======================================================================================
@@ -634,7 +650,7 @@ k_encode_bits(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads,
         } else {
             if (!first && prev + 1u < p_end) return prev + 1u;
             uint32_t v = 0;
-            if (lane == 0) v = atomicAdd(P.next_pkt + 1, P.grab_enc);
+            if (lane == 0) v = atomicAdd(P.next_pkt + 2, P.grab_enc);
             v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
             p_end = v + P.grab_enc;
             return v;
@@ -656,6 +672,7 @@ k_encode_bits(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads,
         }
         wave_sync();
     }
+    if constexpr (!UNIFORM) sign_off(P.next_pkt + 2, gridDim.x * ENC_WAVES, lane);
 }
 
 // ======================================================================================
@@ -1013,6 +1030,7 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ in, float2 *__restri
             }
         }
     }
+    if constexpr (!UNIFORM) sign_off(P.next_pkt, gridDim.x * (uint32_t)n_wv, lane);
 }
 
 }  // namespace
@@ -1364,6 +1382,7 @@ int ofdmtx_plan_ragged(ofdmtx_ctx *ctx, uint64_t n_pkts, const uint8_t *regimes,
     // the fused kernel's work counter sits behind the row table, on a 256-byte line of its own
     const size_t counter_at = (((size_t)n_pkts + 1) * sizeof(uint32_t) + 255u) & ~(size_t)255u;
     if (e == hipSuccess) e = hipMalloc(&pl->d_row_start, counter_at + 256);
+    if (e == hipSuccess) e = hipMemset(reinterpret_cast<uint8_t *>(pl->d_row_start) + counter_at, 0, 256);
     if (e == hipSuccess && n_pkts)
         e = hipMemcpy(pl->d_recs, pl->recs.data(), n_pkts * sizeof(PktRec), hipMemcpyHostToDevice);
     if (e == hipSuccess)
@@ -1378,11 +1397,14 @@ int ofdmtx_plan_ragged(ofdmtx_ctx *ctx, uint64_t n_pkts, const uint8_t *regimes,
     pp.row_start = pl->d_row_start;
     pp.next_pkt = pl->d_row_start + counter_at / sizeof(uint32_t);
     // packets per draw: about 128 output rows (80 KB of samples) for k_tx, eight times as many
-    // packets for the much cheaper k_encode_bits; 1 for batches of ordinary packets
+    // packets for the much cheaper k_encode_bits; 1 for batches of ordinary packets, and never so
+    // many that a small batch would be left to a few waves
     {
         const uint64_t avg_rows = n_pkts ? (rows + n_pkts - 1) / n_pkts : 1;
-        pp.grab_tx = (uint32_t)(avg_rows >= 128 ? 1 : 128 / (avg_rows ? avg_rows : 1));
-        pp.grab_enc = 8u * pp.grab_tx;
+        const uint64_t by_rows = avg_rows >= 128 ? 1 : 128 / (avg_rows ? avg_rows : 1);
+        const uint64_t by_count = n_pkts / 16384u > 0 ? n_pkts / 16384u : 1;
+        pp.grab_tx = (uint32_t)(by_rows < by_count ? by_rows : by_count);
+        pp.grab_enc = (uint32_t)(8u * by_rows < by_count ? 8u * by_rows : by_count);
     }
     *out = pl;
     return OFDMTX_OK;
@@ -1464,7 +1486,6 @@ int ofdmtx_encode_bits(ofdmtx_ctx *ctx, const ofdmtx_plan *pl, const uint8_t *d_
     hipLaunchKernelGGL((k_encode_bits<U_, R_>), dim3(grid), dim3(64 * ENC_WAVES), 0, st, pp, tab,    \
                        d_payloads, d_plcp, d_scrambled, d_coded, d_interleaved)
     if (!pp.uniform) {
-        HIPCHK(hipMemsetAsync(pp.next_pkt + 1, 0, sizeof(uint32_t), st));
         LAUNCH_ENC(false, 0);
     } else {
         switch (pp.regime) {
@@ -1524,7 +1545,6 @@ static int launch_tx(ofdmtx_ctx *ctx, const ofdmtx_plan *pl, const uint8_t *d_in
                            tab, d_in, mapped, iq, a_words, u_off, wave_words);                       \
     } while (0)
     const bool pnc = (pp.flags & (OFDMTX_F_PNC_A | OFDMTX_F_PNC_B)) || pp.pilot_mode >= OFDMTX_PILOT_PNC_A;
-    if (!pp.uniform) HIPCHK(hipMemsetAsync(pp.next_pkt, 0, sizeof(uint32_t), st));
     if (pnc) {
         if (pp.uniform) LAUNCH_TX(true, 0, true); else LAUNCH_TX(false, 0, true);
     } else if (!pp.uniform) {
