@@ -110,6 +110,7 @@ CASES = [
     dict(fft_length=512, occupied_tones=416, cp_length=64),
     dict(fft_length=1024, occupied_tones=832, cp_length=256),
     dict(fft_length=1024, occupied_tones=832, cp_length=128, num_preambles=3),
+    dict(fft_length=1024, occupied_tones=832, cp_length=16),
     dict(fft_length=256, occupied_tones=100, cp_length=7),           # odd row length, narrow band
     dict(fft_length=64, occupied_tones=52, cp_length=0),
 ]

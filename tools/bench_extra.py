@@ -105,7 +105,7 @@ def main():
     # variable-size modulator: frames of 16 data symbols + 3 preamble symbols, unit QPSK
     class O(object):
         num_preambles, half_sync, verbose, log = 2, True, False, False
-    for nfft, cp in ((256, 64), (256, 32), (1024, 256), (1024, 128), (64, 16)):
+    for nfft, cp in ((256, 64), (256, 32), (256, 16), (1024, 256), (1024, 128), (1024, 16), (64, 16)):
         o = O()
         o.fft_length, o.occupied_tones, o.cp_length = nfft, int(0.8125 * nfft), cp
         p = raw.ofdm_params(o)
