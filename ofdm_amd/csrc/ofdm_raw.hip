@@ -104,6 +104,63 @@ constexpr int bit_reverse(int i, int n)
 
 constexpr int RAW_WAVES = 4;
 
+// Steps 1b-3 of the N = L * M point modulator for the S = max(L, M) lanes of one symbol (lane t of
+// the symbol, symbol area T, wave's first area T_wave with SPW areas of TS float2 each):
+//   bin k = l + L m of the (DC-centred) input:  x[M q + p] = sum_l W_L^{l q} W_N^{l p} sum_m X[l + L m] W_M^{m p}
+// On entry lane t < L holds its M bins in x, bit-reversed.  step 1b: M-point transforms in
+// registers, times W_N^{l p} / sqrt(N), to LDS; step 2: lane p < M reads the L partial results,
+// transforms them and puts its samples M q + p, cyclic prefix included, back into the area as one
+// output row; step 3: the wave stores the rows with 16 bytes per lane, consecutive over the lanes.
+// All lanes of the wave must call it (wave-level hand-overs inside).
+template <int L, int M>
+__device__ __forceinline__ void raw_transform_store(bool active, int t, int lane, uint32_t row, v2f (&x)[M], v2f *T,
+                                                    const v2f *T_wave, int TS, const v2f *s_tw, uint32_t n, uint32_t cp,
+                                                    float2 *__restrict__ iq)
+{
+    constexpr int N = L * M, S = L > M ? L : M, SPW = 64 / S;
+    const uint32_t row_len = n + cp;
+    if (active && t < L) {
+        idft_reg<M>(x);
+#pragma unroll
+        for (int p = 0; p < M; p++) T[p * (L + 1) + t] = cmul(x[p], s_tw[(t * p) & (N - 1)]);
+    }
+    wave_sync();
+    // ---- step 2: L-point transforms, cyclic prefix (gr-digital ofdm_cyclic_prefixer,
+    // rawofdm/src/python/raw_ofdm_mod.py:47)
+    v2f y[L];
+    if (active && t < M) {
+#pragma unroll
+        for (int l = 0; l < L; l++) y[bit_reverse(l, L)] = T[t * (L + 1) + l];
+        idft_reg<L>(y);
+    }
+    wave_sync();                                              // the partial results are consumed
+    if (active && t < M && row != ROW_DROPPED) {
+        const uint32_t tail = n - cp;                         // samples >= tail are repeated in front
+#pragma unroll
+        for (int q = 0; q < L; q++) {
+            const uint32_t k = (uint32_t)(M * q + t);
+            T[cp + k] = y[q];
+            if (k >= tail) T[k - tail] = y[q];
+        }
+    }
+    wave_sync();
+    // ---- step 3: rows to memory (a row starts on a 16-byte boundary when row_len is even)
+#pragma unroll
+    for (int sl = 0; sl < SPW; sl++) {
+        const uint32_t row_s = __shfl(row, sl * S);           // the row of slot sl
+        if (row_s == ROW_DROPPED) continue;
+        const v2f *Ts = T_wave + sl * TS;
+        float2 *o = iq + (size_t)row_s * row_len;
+        if ((row_len & 1u) == 0u) {
+            const float4 *src4 = reinterpret_cast<const float4 *>(Ts);
+            float4 *dst4 = reinterpret_cast<float4 *>(o);
+            for (uint32_t i = lane; i < row_len / 2; i += 64) dst4[i] = src4[i];
+        } else {
+            for (uint32_t i = lane; i < row_len; i += 64) o[i] = make_float2(Ts[i].x, Ts[i].y);
+        }
+    }
+}
+
 // One work item per wavefront and iteration: either 64 / max(L, M) OFDM symbols (items
 // 0 .. n_groups-1) or the copy of one frame's preamble rows (the items after those).
 //   bin k = l + L m of the (DC-centred) input:  x[M q + p] = sum_l W_L^{l q} W_N^{l p} sum_m X[l + L m] W_M^{m p}
@@ -162,9 +219,9 @@ k_raw_modulate(RawParams R, const float2 *__restrict__ data, float2 *__restrict_
             row = R.frame_size ? (sym / R.frame_size) * (R.frame_size + R.n_pre) + R.n_pre + sym % R.frame_size
                                : R.sym_row[sym];
 
-        // ---- step 1: carrier map (rawofdm/src/lib/ofdm/raw_ofdm_mapper.cc:53-78) and M-point transforms
+        // ---- step 1: carrier map (rawofdm/src/lib/ofdm/raw_ofdm_mapper.cc:53-78)
+        v2f x[M];
         if (active && t < L) {
-            v2f x[M];
             const float2 *dsym = data + (size_t)sym * R.data_tones;
             // all loads first, nothing between them that could make the compiler wait for one
             // load before it issues the next (a tap store in this loop did exactly that)
@@ -187,46 +244,9 @@ k_raw_modulate(RawParams R, const float2 *__restrict__ data, float2 *__restrict_
                     mapped[(size_t)sym * N + ((t + L * m + N / 2) & (N - 1))] = make_float2(v.x, v.y);
                 }
             }
-            idft_reg<M>(x);
-#pragma unroll
-            for (int p = 0; p < M; p++) T[p * (L + 1) + t] = cmul(x[p], s_tw[(t * p) & (N - 1)]);
         }
-        wave_sync();
-
-        // ---- step 2: L-point transforms, cyclic prefix (gr-digital ofdm_cyclic_prefixer,
-        // rawofdm/src/python/raw_ofdm_mod.py:47) and stores
-        v2f y[L];
-        if (active && t < M) {
-#pragma unroll
-            for (int l = 0; l < L; l++) y[bit_reverse(l, L)] = T[t * (L + 1) + l];
-            idft_reg<L>(y);
-        }
-        wave_sync();                                              // the partial results are consumed
-        if (active && t < M && row != ROW_DROPPED) {
-            const uint32_t tail = R.n - R.cp;                     // samples >= tail are repeated in front
-#pragma unroll
-            for (int q = 0; q < L; q++) {
-                const uint32_t n = (uint32_t)(M * q + t);
-                T[R.cp + n] = y[q];
-                if (n >= tail) T[n - tail] = y[q];
-            }
-        }
-        wave_sync();
-        // ---- step 3: rows to memory (a row starts on a 16-byte boundary when row_len is even)
-#pragma unroll
-        for (int sl = 0; sl < SPW; sl++) {
-            const uint32_t row_s = __shfl(row, sl * S);           // the row of slot sl
-            if (row_s == ROW_DROPPED) continue;
-            const v2f *Ts = s_t + (wave * SPW + sl) * TS;
-            float2 *o = iq + (size_t)row_s * row_len;
-            if ((row_len & 1u) == 0u) {
-                const float4 *src4 = reinterpret_cast<const float4 *>(Ts);
-                float4 *dst4 = reinterpret_cast<float4 *>(o);
-                for (uint32_t i = lane; i < row_len / 2; i += 64) dst4[i] = src4[i];
-            } else {
-                for (uint32_t i = lane; i < row_len; i += 64) o[i] = make_float2(Ts[i].x, Ts[i].y);
-            }
-        }
+        raw_transform_store<L, M>(active, t, lane, active ? row : ROW_DROPPED, x, T, s_t + wave * SPW * TS, TS, s_tw, R.n,
+                                  R.cp, iq);
         wave_sync();
     }
 }
