@@ -184,6 +184,7 @@ class ofdm_mod(object):
         self.params = ofdm_params(options)
         self.ctx = ctx if ctx is not None else TxContext(device)
         self._log = bool(getattr(options, "log", False))
+        self.fused = False          # whether the last modulate_bytes ran as one kernel
 
     def _finish(self, plan, data):
         if self._log:                                               # raw_ofdm_mod.py:54-57 ("tx-map.dat")
@@ -212,6 +213,35 @@ class ofdm_mod(object):
         plan = plan_frames(self.ctx, p.fft_length, p.cp_length, p.padded_carriers, p.padded_preambles,
                            n_sym // frame_size, frame_size)
         return self._finish(plan, data)
+
+    def modulate_bytes(self, bitrate, data, nsymbols, out=None):
+        """qam_tx(bitrate, data_tones, nsymbols) feeding modulate_frames (rawofdm/examples/
+        ofdm_rxtx.py:63-87), in one kernel where the geometry allows (the carrier values then
+        never pass through memory), else as the two calls.  data: whole frames of
+        qam_tx(...).framebytes bytes."""
+        p = self.params
+        tx = qam_tx(bitrate, p.data_tones, nsymbols, ctx=self.ctx)
+        dev = self.ctx.device
+        if not torch.is_tensor(data):
+            data = torch.frombuffer(bytearray(bytes(data)) or bytearray(1), dtype=torch.uint8)
+        data = data.to(dev).contiguous().reshape(-1)
+        if data.dtype != torch.uint8 or data.numel() % tx.framebytes:
+            raise ValueError("data must be uint8 and hold whole frames of %d bytes" % tx.framebytes)
+        n_frames = data.numel() // tx.framebytes
+        plan = plan_frames(self.ctx, p.fft_length, p.cp_length, p.padded_carriers, p.padded_preambles, n_frames, nsymbols)
+        iq = out if out is not None else torch.empty(plan.n_samples, dtype=torch.complex64, device=dev)
+        if iq.numel() < plan.n_samples or iq.dtype != torch.complex64:
+            raise ValueError("iq buffer must be complex64 with >= %d samples" % plan.n_samples)
+        rc = _lib.ESHAPE
+        self.fused = False
+        if not self._log:
+            rc = self.ctx._lib.ofdmtx_raw_tx(self.ctx._h, plan._h, tx.qambits, tx.nc, tx.np, _ptr(data), _ptr(iq),
+                                             _stream(dev))
+        if rc == _lib.ESHAPE:
+            return self._finish(plan, tx.modulate(data)) if out is None else plan.modulate(tx.modulate(data), out=out)
+        _lib.check(rc)
+        self.fused = True
+        return iq
 
     add_options = staticmethod(ofdm_params.add_options)
 

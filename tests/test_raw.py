@@ -344,6 +344,47 @@ def test_gpu_bytes_to_iq_and_back(txctx, bitrate, nfft):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nfft,cp", [(64, 16), (128, 32), (256, 64), (256, 7), (512, 64), (1024, 256), (1024, 16)])
+def test_gpu_bytes_to_iq_in_one_kernel(txctx, nfft, cp):
+    """ofdm_mod.modulate_bytes (one kernel: bit chain + modulator) gives exactly the samples of
+    qam_tx followed by modulate_frames, at every rate; frames enough for several passes."""
+    import torch
+    from ofdm_amd import raw
+    opt = ro.Options(fft_length=nfft, occupied_tones=int(0.8125 * nfft), cp_length=cp)
+    mod = raw.ofdm_mod(opt, ctx=txctx)
+    p = mod.params
+    assert p.data_tones % 16 == 0
+    rng = np.random.default_rng(nfft + cp)
+    for bitrate in range(1, 9):
+        nsymbols = 16 if nfft < 1024 else 4
+        n_frames = 700 if nfft <= 128 else 150
+        tx = raw.qam_tx(bitrate, p.data_tones, nsymbols, ctx=txctx)
+        data = torch.from_numpy(rng.integers(0, 256, n_frames * tx.framebytes, dtype=np.uint8)).to(txctx.device)
+        mod.fused = False
+        got = mod.modulate_bytes(bitrate, data, nsymbols)
+        assert mod.fused == (nfft <= 512), "one kernel up to N = 512, the two kernels above"
+        want = mod.modulate_frames(tx.modulate(data), nsymbols)
+        assert torch.equal(got.view(torch.float32), want.view(torch.float32)), (bitrate, nfft)
+
+
+@pytest.mark.gpu
+def test_gpu_bytes_to_iq_falls_back(txctx):
+    """A carrier count off the 16 grid: modulate_bytes runs the two kernels and says so."""
+    import torch
+    from ofdm_amd import raw
+    opt = ro.Options(fft_length=64, occupied_tones=44, cp_length=16)
+    mod = raw.ofdm_mod(opt, ctx=txctx)
+    p = mod.params
+    assert p.data_tones == 40
+    tx = raw.qam_tx(5, p.data_tones, 8, ctx=txctx)
+    data = torch.from_numpy(np.random.default_rng(1).integers(0, 256, 9 * tx.framebytes, dtype=np.uint8)).to(txctx.device)
+    mod.fused = False
+    got = mod.modulate_bytes(5, data, 8)
+    assert not mod.fused
+    assert torch.equal(got.view(torch.float32), mod.modulate_frames(tx.modulate(data), 8).view(torch.float32))
+
+
+@pytest.mark.gpu
 def test_gpu_qam_tx_rejects_bad_geometry(txctx):
     from ofdm_amd import _lib, raw
     with pytest.raises(AssertionError):            # raw_qam.py:35

@@ -49,12 +49,14 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--ragged-packets", type=int, default=400_000)
     ap.add_argument("--raw-symbols", type=int, default=1 << 20)
-    ap.add_argument("--only", choices=["qam"], default=None, help="run one section only")
+    ap.add_argument("--only", choices=["qam", "chain"], default=None, help="run one section only")
     a = ap.parse_args()
     ctx = TxContext(0)
     dev = ctx.device
     if a.only == "qam":
         return bench_qam_tx(ctx, a.steps)
+    if a.only == "chain":
+        return bench_raw_chain(ctx, a.steps)
 
     # mixed-rate ragged batch: all eight rates, payload lengths 1..2304 bytes
     rng = np.random.default_rng(3)
@@ -121,6 +123,7 @@ def main():
              {"data_symbols": n_frames * 16})
         del iq, data, plan
     bench_qam_tx(ctx, a.steps)
+    bench_raw_chain(ctx, a.steps)
 
 
 def bench_qam_tx(ctx, steps):
@@ -134,6 +137,34 @@ def bench_qam_tx(ctx, steps):
         ms = timed(lambda: tx.modulate(data, out=out), steps)
         line("rawofdm qam_tx bitrate %d, %d carriers x 16 symbols per frame, %d frames" % (bitrate, ncar, n_frames),
              ms, data.numel() + out.numel() * 8, out.numel(), {"frames": n_frames})
+
+
+def bench_raw_chain(ctx, steps):
+    """bytes -> IQ for rawofdm: the two kernels with the carrier values in memory against the one-kernel path"""
+    dev = ctx.device
+
+    class O(object):
+        num_preambles, half_sync, verbose, log = 2, True, False, False
+    for bitrate, nfft, cp in ((8, 256, 64), (5, 256, 64), (1, 256, 64), (8, 128, 32), (8, 512, 128), (8, 1024, 256), (8, 64, 16), (3, 64, 16)):
+        o = O()
+        o.fft_length, o.occupied_tones, o.cp_length = nfft, int(0.8125 * nfft), cp
+        mod = raw.ofdm_mod(o, ctx=ctx)
+        p = mod.params
+        nsym = 16
+        n_frames = ((1 << 20) if nfft <= 256 else (1 << 18)) // nsym
+        tx = raw.qam_tx(bitrate, p.data_tones, nsym, ctx=ctx)
+        data = torch.randint(0, 256, (n_frames * tx.framebytes,), dtype=torch.uint8, device=dev)
+        plan = raw.plan_frames(ctx, p.fft_length, p.cp_length, p.padded_carriers, p.padded_preambles, n_frames, nsym)
+        iq = torch.empty(plan.n_samples, dtype=torch.complex64, device=dev)
+        vals = torch.empty(n_frames * nsym * p.data_tones, dtype=torch.complex64, device=dev)
+
+        def two():
+            tx.modulate(data, out=vals)
+            plan.modulate(vals, out=iq)
+        ms2 = timed(two, steps)
+        ms1 = timed(lambda: mod.modulate_bytes(bitrate, data, nsym, out=iq), steps)
+        line("rawofdm bytes -> IQ in one kernel, bitrate %d, N=%d cp=%d, %d frames of %d symbols" % (bitrate, nfft, cp, n_frames, nsym),
+             ms1, data.numel() + plan.n_samples * 8, plan.n_samples, {"two_kernels_ms": ms2, "fused": bool(mod.fused)})
 
 
 if __name__ == "__main__":
