@@ -143,6 +143,16 @@ int ofdmtx_plan_ragged(ofdmtx_ctx *ctx, uint64_t n_pkts, const uint8_t *regimes,
                        const uint32_t *payload_len, const uint64_t *payload_off,
                        double symbol_time, int pilot_mode, uint32_t pilot_start, unsigned flags,
                        float amp, ofdmtx_plan **out);
+/* The same plan from DEVICE arrays (d_payload_off may be NULL), built by kernels: geometry per
+ * packet, prefix sums for every offset, records -- no per-packet host work (the host loop of
+ * ofdmtx_plan_ragged costs about 18 ns per packet).  Enqueues on `stream` and waits for it (the
+ * totals come back to the host).  Lengths are uint32 as above; an invalid regime or length in any
+ * packet fails the whole call (OFDMTX_EREGIME / OFDMTX_ELENGTH).  No counterpart in the reference,
+ * whose flowgraph is sized for one packet length (examples/ftw_ofdm.py:129-130). */
+int ofdmtx_plan_ragged_device(ofdmtx_ctx *ctx, uint64_t n_pkts, const uint8_t *d_regimes,
+                              const uint32_t *d_payload_len, const uint64_t *d_payload_off,
+                              double symbol_time, int pilot_mode, uint32_t pilot_start,
+                              unsigned flags, float amp, void *stream, ofdmtx_plan **out);
 int ofdmtx_plan_destroy(ofdmtx_plan *plan);
 int ofdmtx_plan_get_sizes(const ofdmtx_plan *plan, ofdmtx_plan_sizes *out);
 /* Per-packet layout, host arrays of n_pkts entries each (any may be NULL):

@@ -54,6 +54,8 @@ PROTOTYPES = {
                                       C.c_int, C.c_uint32, C.c_uint, C.c_float, C.POINTER(_VP)]),
     "ofdmtx_plan_ragged": (C.c_int, [_VP, C.c_uint64, _VP, _VP, _VP, C.c_double, C.c_int, C.c_uint32,
                                      C.c_uint, C.c_float, C.POINTER(_VP)]),
+    "ofdmtx_plan_ragged_device": (C.c_int, [_VP, C.c_uint64, _VP, _VP, _VP, C.c_double, C.c_int, C.c_uint32,
+                                            C.c_uint, C.c_float, _VP, C.POINTER(_VP)]),
     "ofdmtx_plan_destroy": (C.c_int, [_VP]),
     "ofdmtx_plan_get_sizes": (C.c_int, [_VP, C.POINTER(PlanSizes)]),
     "ofdmtx_plan_get_layout": (C.c_int, [_VP] * 9),

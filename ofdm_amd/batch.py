@@ -63,6 +63,12 @@ class TxContext:
     def plan_ragged(self, regimes, payload_len, payload_off=None, symbol_time=4.0,
                     pilot_mode=_lib.PILOT_REF_STREAM, pilot_start=0,
                     flags=_lib.F_PREAMBLE | _lib.F_ZEROGAP, amp=0.3):
+        """Ragged / mixed-rate plan.  numpy arrays (or lists) are walked on the host; torch tensors
+        on this context's device (uint8 regimes, int32 lengths, optional int64 offsets) are turned
+        into a plan by kernels, without the per-packet host loop."""
+        if torch.is_tensor(regimes) and regimes.is_cuda:
+            return self._plan_ragged_device(regimes, payload_len, payload_off, symbol_time, pilot_mode,
+                                            pilot_start, flags, amp)
         regimes = np.ascontiguousarray(regimes, dtype=np.uint8)
         payload_len = np.ascontiguousarray(payload_len, dtype=np.uint32)
         if len(regimes) != len(payload_len):
@@ -76,6 +82,25 @@ class TxContext:
                                                 off.ctypes.data if off is not None else None,
                                                 float(symbol_time), int(pilot_mode), int(pilot_start),
                                                 int(flags), float(amp), C.byref(h)))
+        return TxPlan(self, h)
+
+
+    def _plan_ragged_device(self, regimes, payload_len, payload_off, symbol_time, pilot_mode, pilot_start, flags, amp):
+        dev = self.device
+        if regimes.dtype != torch.uint8 or regimes.device != dev or not regimes.is_contiguous():
+            raise ValueError("regimes must be a contiguous uint8 tensor on %s" % dev)
+        if (not torch.is_tensor(payload_len) or payload_len.dtype != torch.int32 or payload_len.device != dev or
+                not payload_len.is_contiguous() or payload_len.numel() != regimes.numel()):
+            raise ValueError("payload_len must be a contiguous int32 tensor on %s, one entry per packet" % dev)
+        if payload_off is not None and (not torch.is_tensor(payload_off) or payload_off.dtype != torch.int64 or
+                                        payload_off.device != dev or not payload_off.is_contiguous() or
+                                        payload_off.numel() != regimes.numel()):
+            raise ValueError("payload_off must be a contiguous int64 tensor on %s, one entry per packet" % dev)
+        h = C.c_void_p()
+        _lib.check(self._lib.ofdmtx_plan_ragged_device(self._h, regimes.numel(), _ptr(regimes), _ptr(payload_len),
+                                                       _ptr(payload_off), float(symbol_time), int(pilot_mode),
+                                                       int(pilot_start), int(flags), float(amp), _stream(dev),
+                                                       C.byref(h)))
         return TxPlan(self, h)
 
 

@@ -140,6 +140,9 @@ struct ofdmtx_plan {
     std::vector<uint32_t> plcp_len, msg_len;
     ofdmtx_detail::PktRec *d_recs;
     uint32_t *d_row_start;
+    // plans built on the device: per-packet lengths stay there until the layout is asked for
+    uint32_t *d_plcp_len, *d_msg_len;
+    mutable bool layout_on_host;
     ofdmtx_pkt_info uni;   // uniform geometry
     uint32_t tx_a_words;   // LDS words per wave the fused kernel needs for the largest packet (first region)
     uint32_t tx_u_words;   // ... for the scrambled words of the longest packet (payload input)

@@ -1033,6 +1033,163 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ in, float2 *__restri
     if constexpr (!UNIFORM) sign_off(P.next_pkt, gridDim.x * (uint32_t)n_wv, lane);
 }
 
+// ======================================================================================
+// Plan building on the device (ragged plans from device arrays)
+// ======================================================================================
+
+// Geometry of one packet: the arithmetic of get_info / ftw_make (pu:81-97,160-171), shared by the
+// host entry point and the device-side plan builder.
+struct PktGeom {
+    int n_sym, n_pad, txtime, length, plcp_len, msg_len, n_rows;
+};
+__host__ __device__ __forceinline__ PktGeom pkt_geometry(const RegimeInfo &ri, int payload_len, double symbol_time,
+                                                          unsigned flags)
+{
+    PktGeom g;
+    const int mpdu = 24 + payload_len;
+    const int nbits = 16 + 32 + 6 + 8 * mpdu;
+    g.n_sym = (nbits + ri.n_dbps - 1) / ri.n_dbps;                       // pu:85
+    g.n_pad = g.n_sym * ri.n_dbps - nbits;                               // pu:94-97
+    g.txtime = (int)(5 * symbol_time + symbol_time * g.n_sym) + 2;       // pu:90
+    g.length = mpdu + 4;
+    g.plcp_len = 5 + g.length + (g.n_pad + 6 + 7) / 8;                   // pu:160-171,205
+    g.msg_len = 6 + g.n_sym * ri.n_cbps / 8;
+    g.n_rows = ((flags & OFDMTX_F_PREAMBLE) ? ((flags & (OFDMTX_F_PNC_A | OFDMTX_F_PNC_B)) ? PNC_PRE_ROWS : PRE_ROWS) : 0) +
+               1 + g.n_sym + ((flags & OFDMTX_F_ZEROGAP) ? GAP_ROWS : 0);
+    return g;
+}
+
+constexpr int PLAN_COLS = 5;          // scanned per packet: payload bytes, PLCP stride, message stride, symbols, rows
+constexpr int SCAN_ITEMS = 8;         // per thread
+constexpr int SCAN_BLOCK = 256 * SCAN_ITEMS;
+
+struct PlanDevOut {                   // totals and maxima read back by the host
+    unsigned long long max_plcp_len, max_msg_len, max_n_sym, pay_extent;
+    uint32_t error;                   // bit 0: regime outside 1..8, bit 1: payload too long
+};
+
+// per packet: geometry into the record and the PLAN_COLS columns col[c * pitch + i]
+__global__ void k_plan_geom(uint32_t n, const uint8_t *__restrict__ regimes, const uint32_t *__restrict__ lens,
+                            const uint64_t *__restrict__ pay_off, double symbol_time, unsigned flags,
+                            PktRec *__restrict__ recs, uint32_t *__restrict__ plcp_len, uint32_t *__restrict__ msg_len,
+                            unsigned long long *__restrict__ col, size_t pitch, PlanDevOut *__restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int regime = regimes[i];
+    const uint32_t len = lens[i];
+    uint32_t err = 0;
+    if (regime < 1 || regime > 8) err |= 1u;
+    if (len > (uint32_t)MAXLEN || 24u + len + 4u > (uint32_t)MAXLEN) err |= 2u;
+    if (err) {
+        atomicOr(&out->error, err);
+        return;
+    }
+    const PktGeom g = pkt_geometry(regime_info(regime), (int)len, symbol_time, flags);
+    PktRec r;
+    r.pay_off = pay_off ? pay_off[i] : 0;
+    r.plcp_off = 0;
+    r.msg_off = 0;
+    r.sym_off = 0;
+    r.pay_len = len;
+    r.n_sym = (uint32_t)g.n_sym;
+    r.pilot_base = 0;
+    r.txtime = (uint16_t)((uint32_t)g.txtime & 0xFFFFu);
+    r.regime = (uint8_t)regime;
+    r.pad_ = 0;
+    r.pad2_ = 0;
+    recs[i] = r;
+    plcp_len[i] = (uint32_t)g.plcp_len;
+    msg_len[i] = (uint32_t)g.msg_len;
+    col[0 * pitch + i] = len;
+    col[1 * pitch + i] = ((uint32_t)g.plcp_len + 15u) & ~15u;
+    col[2 * pitch + i] = ((uint32_t)g.msg_len + 15u) & ~15u;
+    col[3 * pitch + i] = (uint32_t)g.n_sym + 1u;
+    col[4 * pitch + i] = (uint32_t)g.n_rows;
+    atomicMax(&out->max_plcp_len, (unsigned long long)g.plcp_len);
+    atomicMax(&out->max_msg_len, (unsigned long long)g.msg_len);
+    atomicMax(&out->max_n_sym, (unsigned long long)g.n_sym);
+    if (pay_off) atomicMax(&out->pay_extent, (unsigned long long)(pay_off[i] + len));
+}
+
+// exclusive scan of every column, in three steps: inside blocks of SCAN_BLOCK items, over the
+// block totals, and the block offsets added back (element n of a column receives the total)
+__global__ void __launch_bounds__(256) k_scan_local(unsigned long long *col, size_t pitch, uint32_t n,
+                                                    unsigned long long *block_sums, uint32_t n_blocks)
+{
+    __shared__ unsigned long long s[256];
+    unsigned long long *c = col + (size_t)blockIdx.y * pitch;
+    const uint32_t base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
+    unsigned long long v[SCAN_ITEMS], sum = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        v[k] = base + k < n ? c[base + k] : 0;
+        sum += v[k];
+    }
+    s[threadIdx.x] = sum;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const unsigned long long t = threadIdx.x >= (unsigned)o ? s[threadIdx.x - o] : 0;
+        __syncthreads();
+        s[threadIdx.x] += t;
+        __syncthreads();
+    }
+    unsigned long long run = s[threadIdx.x] - sum;                // exclusive prefix of this thread
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        if (base + k <= n) c[base + k] = run;                     // (index n: written again by the last step)
+        run += v[k];
+    }
+    if (threadIdx.x == 255) block_sums[(size_t)blockIdx.y * n_blocks + blockIdx.x] = s[255];
+}
+
+__global__ void __launch_bounds__(256) k_scan_sums(unsigned long long *block_sums, uint32_t n_blocks)
+{
+    __shared__ unsigned long long s[256];
+    unsigned long long *b = block_sums + (size_t)blockIdx.x * n_blocks;
+    unsigned long long carry = 0;
+    for (uint32_t base = 0; base < n_blocks; base += 256) {
+        const uint32_t i = base + threadIdx.x;
+        const unsigned long long v = i < n_blocks ? b[i] : 0;
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            const unsigned long long t = threadIdx.x >= (unsigned)o ? s[threadIdx.x - o] : 0;
+            __syncthreads();
+            s[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < n_blocks) b[i] = carry + s[threadIdx.x] - v;
+        carry += s[255];
+        __syncthreads();
+    }
+}
+
+// adds the block offsets and builds the records: offsets, row table, pilot index
+__global__ void k_plan_fill(uint32_t n, unsigned long long *__restrict__ col, size_t pitch,
+                            const unsigned long long *__restrict__ block_sums, uint32_t n_blocks, int have_pay_off,
+                            int pilot_mode, uint32_t pilot_start, PktRec *__restrict__ recs,
+                            uint32_t *__restrict__ row_start)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    unsigned long long v[PLAN_COLS];
+#pragma unroll
+    for (int c = 0; c < PLAN_COLS; c++) {
+        v[c] = col[c * pitch + i] + block_sums[(size_t)c * n_blocks + i / SCAN_BLOCK];
+        col[c * pitch + i] = v[c];
+    }
+    row_start[i] = (uint32_t)v[4];
+    if (i == n) return;
+    PktRec r = recs[i];
+    if (!have_pay_off) r.pay_off = v[0];
+    r.plcp_off = v[1];
+    r.msg_off = v[2];
+    r.sym_off = (uint32_t)v[3];
+    r.pilot_base = pilot_mode == OFDMTX_PILOT_REF_STREAM ? (uint32_t)((pilot_start + v[3]) % 127u) : pilot_start;
+    recs[i] = r;
+}
+
 }  // namespace
 
 thread_local int ofdmtx_g_last_hip = 0;
@@ -1092,20 +1249,19 @@ int ofdmtx_packet_info(int regime, int payload_len, double symbol_time, unsigned
     if (!out || payload_len < 0) return OFDMTX_EINVAL;
     if (regime < 1 || regime > 8) return OFDMTX_EREGIME;
     const RegimeInfo ri = regime_info(regime);
+    const PktGeom g = pkt_geometry(ri, payload_len, symbol_time, flags);
     const int mpdu = 24 + payload_len;
-    const int nbits = 16 + 32 + 6 + 8 * mpdu;
     out->n_cbps = ri.n_cbps;
     out->n_bpsc = ri.n_bpsc;
     out->n_dbps = ri.n_dbps;
-    out->n_sym = (nbits + ri.n_dbps - 1) / ri.n_dbps;                   // pu:85
-    out->n_data = out->n_sym * ri.n_dbps;                               // pu:94
-    out->n_pad = out->n_data - nbits;                                   // pu:97
-    out->txtime = (int)(5 * symbol_time + symbol_time * out->n_sym) + 2;   // pu:90
-    out->length = mpdu + 4;
-    out->plcp_len = 5 + out->length + (out->n_pad + 6 + 7) / 8;         // pu:160-171,205
-    out->msg_len = 6 + out->n_sym * ri.n_cbps / 8;
-    out->n_rows = ((flags & OFDMTX_F_PREAMBLE) ? ((flags & (OFDMTX_F_PNC_A | OFDMTX_F_PNC_B)) ? PNC_PRE_ROWS : PRE_ROWS) : 0) + 1 + out->n_sym +
-                  ((flags & OFDMTX_F_ZEROGAP) ? GAP_ROWS : 0);
+    out->n_sym = g.n_sym;
+    out->n_data = g.n_sym * ri.n_dbps;                                  // pu:94
+    out->n_pad = g.n_pad;
+    out->txtime = g.txtime;
+    out->length = g.length;
+    out->plcp_len = g.plcp_len;
+    out->msg_len = g.msg_len;
+    out->n_rows = g.n_rows;
     // the length limit is ftw_make's (pu:119-121), get_info itself has none: *out is complete either way
     return mpdu + 4 > MAXLEN ? OFDMTX_ELENGTH : OFDMTX_OK;
 }
@@ -1240,6 +1396,18 @@ static bool plan_modes_ok(int pilot_mode, unsigned flags)
     return true;
 }
 
+// packets per draw from a ragged plan's work counters: about 128 output rows (80 KB of samples)
+// for k_tx, eight times as many packets for the much cheaper k_encode_bits; 1 for batches of
+// ordinary packets, and never so many that a small batch would be left to a few waves
+static void size_draws(PlanParams &pp, uint64_t n_pkts, uint64_t rows)
+{
+    const uint64_t avg_rows = n_pkts ? (rows + n_pkts - 1) / n_pkts : 1;
+    const uint64_t by_rows = avg_rows >= 128 ? 1 : 128 / (avg_rows ? avg_rows : 1);
+    const uint64_t by_count = n_pkts / 16384u > 0 ? n_pkts / 16384u : 1;
+    pp.grab_tx = (uint32_t)(by_rows < by_count ? by_rows : by_count);
+    pp.grab_enc = (uint32_t)(8u * by_rows < by_count ? 8u * by_rows : by_count);
+}
+
 static void plan_common(ofdmtx_plan *pl, ofdmtx_ctx *ctx, uint64_t n, int pilot_mode,
                         uint32_t pilot_start, unsigned flags, float amp)
 {
@@ -1253,6 +1421,9 @@ static void plan_common(ofdmtx_plan *pl, ofdmtx_ctx *ctx, uint64_t n, int pilot_
     pl->pp.amp = amp;
     pl->d_recs = nullptr;
     pl->d_row_start = nullptr;
+    pl->d_plcp_len = nullptr;
+    pl->d_msg_len = nullptr;
+    pl->layout_on_host = true;
 }
 
 int ofdmtx_plan_uniform(ofdmtx_ctx *ctx, uint64_t n_pkts, int regime, uint32_t payload_len,
@@ -1396,16 +1567,102 @@ int ofdmtx_plan_ragged(ofdmtx_ctx *ctx, uint64_t n_pkts, const uint8_t *regimes,
     pp.recs = pl->d_recs;
     pp.row_start = pl->d_row_start;
     pp.next_pkt = pl->d_row_start + counter_at / sizeof(uint32_t);
-    // packets per draw: about 128 output rows (80 KB of samples) for k_tx, eight times as many
-    // packets for the much cheaper k_encode_bits; 1 for batches of ordinary packets, and never so
-    // many that a small batch would be left to a few waves
-    {
-        const uint64_t avg_rows = n_pkts ? (rows + n_pkts - 1) / n_pkts : 1;
-        const uint64_t by_rows = avg_rows >= 128 ? 1 : 128 / (avg_rows ? avg_rows : 1);
-        const uint64_t by_count = n_pkts / 16384u > 0 ? n_pkts / 16384u : 1;
-        pp.grab_tx = (uint32_t)(by_rows < by_count ? by_rows : by_count);
-        pp.grab_enc = (uint32_t)(8u * by_rows < by_count ? 8u * by_rows : by_count);
+    size_draws(pp, n_pkts, rows);
+    *out = pl;
+    return OFDMTX_OK;
+}
+
+int ofdmtx_plan_ragged_device(ofdmtx_ctx *ctx, uint64_t n_pkts, const uint8_t *d_regimes,
+                              const uint32_t *d_payload_len, const uint64_t *d_payload_off,
+                              double symbol_time, int pilot_mode, uint32_t pilot_start, unsigned flags,
+                              float amp, void *stream, ofdmtx_plan **out)
+{
+    if (!ctx || !out || (n_pkts && (!d_regimes || !d_payload_len))) return OFDMTX_EINVAL;
+    *out = nullptr;
+    if (!plan_modes_ok(pilot_mode, flags)) return OFDMTX_EINVAL;
+    if (n_pkts >= 0xFFFFFFF0ull) return OFDMTX_ETOOBIG;
+    HIPCHK(hipSetDevice(ctx->device));
+    ofdmtx_plan *pl = new (std::nothrow) ofdmtx_plan();
+    if (!pl) return OFDMTX_ENOMEM;
+    plan_common(pl, ctx, n_pkts, pilot_mode, pilot_start, flags, amp);
+    PlanParams &pp = pl->pp;
+    pp.uniform = 0;
+    pl->layout_on_host = false;
+    const uint32_t n = (uint32_t)n_pkts;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t pitch = (size_t)n + 1;
+    const uint32_t n_blocks = (uint32_t)((pitch + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    const size_t counter_at = (((size_t)n_pkts + 1) * sizeof(uint32_t) + 255u) & ~(size_t)255u;
+    unsigned long long *d_col = nullptr, *d_sums = nullptr;
+    PlanDevOut *d_out = nullptr;
+    PlanDevOut h = {};
+    unsigned long long totals[PLAN_COLS] = {};
+    hipError_t e = hipMalloc(&pl->d_recs, (n_pkts ? n_pkts : 1) * sizeof(PktRec));
+    if (e == hipSuccess) e = hipMalloc(&pl->d_row_start, counter_at + 256);
+    if (e == hipSuccess) e = hipMalloc(&pl->d_plcp_len, (n_pkts ? n_pkts : 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&pl->d_msg_len, (n_pkts ? n_pkts : 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&d_col, PLAN_COLS * pitch * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(&d_sums, (size_t)PLAN_COLS * n_blocks * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(&d_out, sizeof(PlanDevOut));
+    if (e == hipSuccess) e = hipMemsetAsync(reinterpret_cast<uint8_t *>(pl->d_row_start) + counter_at, 0, 256, st);
+    if (e == hipSuccess) e = hipMemsetAsync(d_out, 0, sizeof(PlanDevOut), st);
+    if (e == hipSuccess) e = hipMemsetAsync(d_col, 0, PLAN_COLS * pitch * sizeof(unsigned long long), st);
+    if (e == hipSuccess) {
+        if (n)
+            hipLaunchKernelGGL(k_plan_geom, dim3((n + 255u) / 256u), dim3(256), 0, st, n, d_regimes, d_payload_len,
+                               d_payload_off, symbol_time, flags, pl->d_recs, pl->d_plcp_len, pl->d_msg_len, d_col,
+                               pitch, d_out);
+        hipLaunchKernelGGL(k_scan_local, dim3(n_blocks, PLAN_COLS), dim3(256), 0, st, d_col, pitch, n, d_sums, n_blocks);
+        hipLaunchKernelGGL(k_scan_sums, dim3(PLAN_COLS), dim3(256), 0, st, d_sums, n_blocks);
+        hipLaunchKernelGGL(k_plan_fill, dim3((n + 1u + 255u) / 256u), dim3(256), 0, st, n, d_col, pitch, d_sums, n_blocks,
+                           d_payload_off ? 1 : 0, pilot_mode, pp.pilot_start, pl->d_recs, pl->d_row_start);
+        e = hipGetLastError();
     }
+    if (e == hipSuccess) e = hipMemcpyAsync(&h, d_out, sizeof(h), hipMemcpyDeviceToHost, st);
+    for (int c = 0; c < PLAN_COLS && e == hipSuccess; c++)
+        e = hipMemcpyAsync(&totals[c], d_col + c * pitch + n, sizeof(unsigned long long), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (d_col) (void)hipFree(d_col);
+    if (d_sums) (void)hipFree(d_sums);
+    if (d_out) (void)hipFree(d_out);
+    int rc = OFDMTX_OK;
+    if (e != hipSuccess) {
+        ofdmtx_g_last_hip = (int)e;
+        rc = OFDMTX_EHIP;
+    } else if (h.error & 1u) {
+        rc = OFDMTX_EREGIME;
+    } else if (h.error & 2u) {
+        rc = OFDMTX_ELENGTH;
+    } else if (totals[4] >= 0xFFFFFFF0ull || totals[3] >= 0xFFFFFFF0ull) {
+        rc = OFDMTX_ETOOBIG;
+    }
+    if (rc) {
+        ofdmtx_plan_destroy(pl);
+        return rc;
+    }
+    // LDS needs of the kernels from the maxima (the same expressions as tx_words_for and friends)
+    ofdmtx_pkt_info worst;
+    memset(&worst, 0, sizeof(worst));
+    worst.plcp_len = (int32_t)h.max_plcp_len;
+    worst.msg_len = (int32_t)h.max_msg_len;
+    worst.n_sym = (int32_t)h.max_n_sym;
+    pl->tx_a_words = tx_words_for(worst) > 16u ? tx_words_for(worst) : 16u;
+    pl->tx_u_words = tx_u_words_for(worst) > 16u ? tx_u_words_for(worst) : 16u;
+    pl->tx_m_words = tx_m_words_for(worst) > 16u ? tx_m_words_for(worst) : 16u;
+    pl->max_sym_rows = (uint32_t)h.max_n_sym + 1u;
+    pp.total_rows = (uint32_t)totals[4];
+    ofdmtx_plan_sizes &sz = pl->sizes;
+    sz.n_pkts = n_pkts;
+    sz.payload_bytes = d_payload_off ? h.pay_extent : totals[0];
+    sz.plcp_bytes = totals[1] + 16;
+    sz.msg_bytes = totals[2] + 16;
+    sz.n_symbols = totals[3];
+    sz.n_rows = totals[4];
+    sz.n_samples = totals[4] * SYM_LEN;
+    pp.recs = pl->d_recs;
+    pp.row_start = pl->d_row_start;
+    pp.next_pkt = pl->d_row_start + counter_at / sizeof(uint32_t);
+    size_draws(pp, n_pkts, totals[4]);
     *out = pl;
     return OFDMTX_OK;
 }
@@ -1416,6 +1673,8 @@ int ofdmtx_plan_destroy(ofdmtx_plan *pl)
     (void)hipSetDevice(pl->device);
     if (pl->d_recs) (void)hipFree(pl->d_recs);
     if (pl->d_row_start) (void)hipFree(pl->d_row_start);
+    if (pl->d_plcp_len) (void)hipFree(pl->d_plcp_len);
+    if (pl->d_msg_len) (void)hipFree(pl->d_msg_len);
     delete pl;
     return OFDMTX_OK;
 }
@@ -1433,6 +1692,24 @@ int ofdmtx_plan_get_layout(const ofdmtx_plan *pl, uint64_t *plcp_off, uint64_t *
 {
     if (!pl) return OFDMTX_EINVAL;
     const PlanParams &pp = pl->pp;
+    if (!pl->layout_on_host) {
+        // a plan built on the device: fetch its tables once
+        ofdmtx_plan *m = const_cast<ofdmtx_plan *>(pl);
+        const size_t n = pp.n_pkts;
+        m->recs.resize(n);
+        m->row_start.resize(n + 1);
+        m->plcp_len.resize(n);
+        m->msg_len.resize(n);
+        HIPCHK(hipSetDevice(pl->device));
+        HIPCHK(hipDeviceSynchronize());
+        if (n) {
+            HIPCHK(hipMemcpy(m->recs.data(), pl->d_recs, n * sizeof(PktRec), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(m->plcp_len.data(), pl->d_plcp_len, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(m->msg_len.data(), pl->d_msg_len, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        }
+        HIPCHK(hipMemcpy(m->row_start.data(), pl->d_row_start, (n + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        pl->layout_on_host = true;
+    }
     for (uint64_t i = 0; i < pp.n_pkts; i++) {
         if (pp.uniform) {
             if (plcp_off) plcp_off[i] = i * pp.plcp_stride;

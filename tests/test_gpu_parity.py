@@ -283,6 +283,49 @@ def test_ragged_short_packets(txctx, c_oracle):
         check_plan(plan, buf, lens.tolist(), regs.tolist(), c_oracle, flags, 0.3)
 
 
+@pytest.mark.parametrize("n", [0, 1, 2047, 2048, 2049, 70001])
+def test_device_built_plan_equals_host_built_plan(txctx, n):
+    """ofdmtx_plan_ragged_device (kernels: geometry, prefix sums, records) against the host walk
+    of ofdmtx_plan_ragged: same sizes, same per-packet layout, same samples; with and without
+    explicit payload offsets; block boundaries of the scan (2048 items) included."""
+    rng = np.random.default_rng(25 + n)
+    regs = rng.integers(1, 9, n).astype(np.uint8)
+    lens = rng.integers(0, 600, n).astype(np.uint32)
+    if n > 2:
+        lens[:3] = [0, 3140, 2304]
+    for with_off in (False, True):
+        off = None
+        if with_off:
+            gaps = rng.integers(0, 5, n).astype(np.uint64)
+            off = (np.cumsum(lens.astype(np.uint64) + gaps) - lens).astype(np.uint64)      # increasing, with holes
+        kw = dict(symbol_time=8.0, pilot_mode=_lib.PILOT_REF_STREAM, pilot_start=31, flags=3, amp=0.3)
+        host = txctx.plan_ragged(regs, lens, payload_off=off, **kw)
+        dev = txctx.plan_ragged(torch.from_numpy(regs).to(txctx.device), torch.from_numpy(lens.astype(np.int32)).to(txctx.device),
+                                payload_off=None if off is None else torch.from_numpy(off.astype(np.int64)).to(txctx.device), **kw)
+        for k in ("n_pkts", "payload_bytes", "plcp_bytes", "msg_bytes", "n_symbols", "n_rows", "n_samples"):
+            assert getattr(host, k) == getattr(dev, k), k
+        lh, ld = host.layout(), dev.layout()
+        for k in lh:
+            assert np.array_equal(lh[k], ld[k]), k
+        if n:
+            pay = torch.from_numpy(rng.integers(0, 256, max(host.payload_bytes, 1), dtype=np.uint8)).to(txctx.device)
+            a, b = host.tx(pay), dev.tx(pay)
+            assert torch.equal(a.view(torch.float32), b.view(torch.float32))
+            # (tap buffers have unwritten padding between packets: compare the packets' bytes)
+            ta = {k: v.cpu().numpy() for k, v in host.encode_bits(pay, taps=True).items()}
+            tb = {k: v.cpu().numpy() for k, v in dev.encode_bits(pay, taps=True).items()}
+            for i in list(range(min(n, 40))) + list(rng.integers(0, n, 40)):
+                mo, ml, po, pn = (int(lh[k][i]) for k in ("msg_off", "msg_len", "plcp_off", "plcp_len"))
+                assert all(np.array_equal(ta[k][mo:mo + ml], tb[k][mo:mo + ml]) for k in ("coded", "interleaved"))
+                assert all(np.array_equal(ta[k][po:po + pn], tb[k][po:po + pn]) for k in ("plcp", "scrambled"))
+    bad = torch.from_numpy(np.array([1, 9, 3], np.uint8)).to(txctx.device)
+    with pytest.raises(_lib.OfdmTxError):
+        txctx.plan_ragged(bad, torch.tensor([5, 5, 5], dtype=torch.int32, device=txctx.device))
+    with pytest.raises(ValueError):
+        txctx.plan_ragged(torch.from_numpy(np.array([1, 2], np.uint8)).to(txctx.device),
+                          torch.tensor([5, 3141], dtype=torch.int32, device=txctx.device))
+
+
 def test_custom_constellation(txctx, c_oracle):
     """The `constellation` argument of ftw.ofdm_mapper (ftw/ftw.i:157-163): replaced points show up
     in the mapper tap and in the IQ; the SIGNAL symbol keeps its fixed BPSK."""

@@ -19,3 +19,13 @@ for n in (100_000, 1_000_000):
 t = time.perf_counter()
 plan = ctx.plan_uniform(1_000_000, 8, 1500)
 print("plan_uniform 1e6: %.3f ms" % ((time.perf_counter() - t) * 1e3))
+import torch
+for n in (100_000, 1_000_000):
+    regs = torch.randint(1, 9, (n,), dtype=torch.uint8, device=ctx.device)
+    lens = torch.randint(1, 2305, (n,), dtype=torch.int32, device=ctx.device)
+    torch.cuda.synchronize()
+    for _ in range(2):
+        t = time.perf_counter()
+        plan = ctx.plan_ragged(regs, lens)
+        dt = time.perf_counter() - t
+    print("plan_ragged on the device %d packets: %.2f ms" % (n, dt * 1e3))
