@@ -241,7 +241,9 @@ __device__ __forceinline__ void encode_data_symbols(const uint32_t *U, uint32_t 
 
 // Steps 1-3 for one packet, executed by one wavefront: the scrambled PLCP stream as MSB-first
 // words in U[0 .. n_words].  A: >= n_words + 3 words of LDS (natural-order MPDU, dead afterwards);
-// U: >= n_words + 2 words.  plcp_out / scr_out are optional taps (global memory).
+// U: >= n_words + 2 words.  plcp_out / scr_out are optional taps (global memory).  K: rounds of
+// 64 payload words loaded before the first is used.
+template <int K>
 __device__ __forceinline__ void scramble_packet(const Pkt &k, const RegimeInfo &ri, const DevTables &T,
                                                 const uint8_t *__restrict__ payloads, uint32_t *A, uint32_t *U,
                                                 const uint32_t *s_crc, const uint32_t *s_scr, int lane_in,
@@ -282,7 +284,6 @@ __device__ __forceinline__ void scramble_packet(const Pkt &k, const RegimeInfo &
         const uint32_t *q = reinterpret_cast<const uint32_t *>(pp - al);
         const uint32_t n_pw = n_dw - 6u;                                     // payload dwords, the last may be partial
         const uint32_t total = n_words + 3u - 8u;                            // words behind the header to write
-        constexpr int K = 8;
         for (uint32_t j0 = (uint32_t)lane; j0 < total; j0 += 64u * K) {
             uint32_t lo[K], hi[K];
 #pragma unroll
@@ -376,7 +377,7 @@ __device__ __forceinline__ void encode_packet(const Pkt &k, const RegimeInfo &ri
                                      const uint32_t *s_crc, const uint32_t *s_scr, int lane,
                                      uint8_t *plcp_out, uint8_t *scr_out, uint8_t *cod_out)
 {
-    scramble_packet(k, ri, T, payloads, A, U, s_crc, s_scr, lane, plcp_out, scr_out);
+    scramble_packet<8>(k, ri, T, payloads, A, U, s_crc, s_scr, lane, plcp_out, scr_out);
 
     SEC("e4_signal");
     // ---- 4. SIGNAL symbol: 48 coded bits, N = 48 first permutation only (pu:245-249)
@@ -909,7 +910,7 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ in, float2 *__restri
             }
             wave_sync();
         } else {
-            scramble_packet(k, ri, T, in, A, U, s_crc, s_scr, lane, nullptr, nullptr);
+            scramble_packet<8>(k, ri, T, in, A, U, s_crc, s_scr, lane, nullptr, nullptr);
         }
 
         SEC("copy");
