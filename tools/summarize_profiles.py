@@ -33,8 +33,9 @@ if os.path.exists(b):
 
 
 def short(name):
-    if "k_tx" in name:      # k_tx<UNIFORM, REGIME, FROM_MSG>: the message-input instantiation is its own line
-        return "k_tx_msg" if name.split(">(")[0].rstrip().endswith("true") else "k_tx"
+    if "k_tx<" in name:     # k_tx<UNIFORM, REGIME, FROM_MSG, PNC>: the message-input instantiation is its own line
+        args = [a.strip() for a in name.split("k_tx<", 1)[1].split(">", 1)[0].split(",")]
+        return "k_tx_msg" if len(args) > 2 and args[2] == "true" else "k_tx"
     for k in ("k_encode_bits", "k_raw_modulate"):
         if k in name:
             return k
