@@ -464,24 +464,77 @@ struct RowWalk {
 
 // GROUPED (ncarriers a multiple of 16): a thread takes the QB units behind carriers c', c' + G,
 // .. c' + 15 G (G = ncarriers / 16) -- they are the 16 bit positions of the same units -- so every
-// bit position, rotation and shift below is a compile-time constant.
-template <int QB, int S, int B>
-__device__ __forceinline__ uint32_t axis_index(const uint32_t (&h)[QB == 1 ? 1 : QB], int a)
-{
-    // output bit t of the group is stream bit (t + b) % S of the group; first bit = MSB
-    uint32_t idx = 0;
+// bit position, rotation and shift below is a compile-time constant.  The units are never
+// materialised: the encoder leaves its two output streams A and B (one bit per input bit each)
+// as separate MSB-first word rows, and bit b of unit m is looked up where puncturing took it from:
+//   rate 1/2 (keep 4 of 4): punctured bit k = coded bit k      -> stream b & 1, input bit 8 m + b / 2
+//   rate 3/4 (keep 4 of 6): coded bit 6 (k / 4) + k % 4         -> stream b & 1, input bit 12 m + 3 (b / 4) + (b % 4) / 2
+//   rate 2/3 (keep 3 of 4): coded bit 4 (k / 3) + k % 3, k = 16 m + b; three units span 32 input bits
+//                            -> with j = 16 (m % 3) + b: stream (j % 3) & 1, input bit 32 (m / 3) + 2 (j / 3) + (j % 3) / 2
+// (rawofdm/src/lib/qam/raw_conv.cc:150-159).  A thread first loads the stream pieces behind its
+// QB units: QB bytes, QB 12-bit windows, or -- rate 2/3, where QB = 6 makes m % 3 = u % 3 -- two words.
+template <int QB, int NC, int NP>
+struct UnitBits {
+    static constexpr int NPIECE = (NC == 4 && NP == 3) ? 2 : (QB == 1 ? 1 : QB);
+    uint32_t a[NPIECE], b[NPIECE];
+
+    __device__ __forceinline__ void load(const uint32_t *SA, const uint32_t *SB, uint32_t cprime)
+    {
+        if constexpr (NC == 4 && NP == 4) {
+            const uint8_t *ba = reinterpret_cast<const uint8_t *>(SA), *bb = reinterpret_cast<const uint8_t *>(SB);
 #pragma unroll
-    for (int t = 0; t < S; t++) idx |= ((h[a * S + (t + B) % S] >> (15 - B)) & 1u) << (S - 1 - t);
-    return idx;
+            for (int u = 0; u < QB; u++) {
+                const uint32_t m = (uint32_t)QB * cprime + (uint32_t)u;       // byte m of an MSB-first word row
+                a[u] = ba[m ^ 3u];
+                b[u] = bb[m ^ 3u];
+            }
+        } else if constexpr (NC == 6) {
+#pragma unroll
+            for (int u = 0; u < QB; u++) {
+                const uint32_t off = 12u * ((uint32_t)QB * cprime + (uint32_t)u), i = off >> 5, sh = off & 31u;
+                a[u] = (sh ? __funnelshift_l(SA[i + 1], SA[i], sh) : SA[i]) >> 20;
+                b[u] = (sh ? __funnelshift_l(SB[i + 1], SB[i], sh) : SB[i]) >> 20;
+            }
+        } else {
+            static_assert(QB == 6, "rate 2/3 is tabulated for 64-QAM only");
+            a[0] = SA[2u * cprime];
+            a[1] = SA[2u * cprime + 1u];
+            b[0] = SB[2u * cprime];
+            b[1] = SB[2u * cprime + 1u];
+        }
+    }
+
+    template <int U, int B>
+    __device__ __forceinline__ uint32_t bit() const                       // bit B of unit U
+    {
+        if constexpr (NC == 4 && NP == 4) {
+            return (((B & 1) ? b[U] : a[U]) >> (7 - B / 2)) & 1u;
+        } else if constexpr (NC == 6) {
+            constexpr int o = 3 * (B / 4) + (B % 4) / 2;
+            return (((B & 1) ? b[U] : a[U]) >> (11 - o)) & 1u;
+        } else {
+            constexpr int j = 16 * (U % 3) + B, n_off = 2 * (j / 3) + (j % 3) / 2;
+            return ((((j % 3) & 1) ? b[U / 3] : a[U / 3]) >> (31 - n_off)) & 1u;
+        }
+    }
+};
+
+// index of one axis (A = 0: I, 1: Q) of the carrier at bit position B: output bit t of the group
+// is stream bit (t + B) % S of the group; first bit = MSB
+template <int QB, int NC, int NP, int S, int B, int A, int... T>
+__device__ __forceinline__ uint32_t axis_index(const UnitBits<QB, NC, NP> &ub, std::integer_sequence<int, T...>)
+{
+    return ((ub.template bit<A * S + (T + B) % S, B>() << (S - 1 - T)) | ...);
 }
 
 // one byte per carrier value: (I index << 3) | Q index
-template <int QB, int S, int... B>
-__device__ __forceinline__ void emit_unit_group(const uint32_t (&h)[QB == 1 ? 1 : QB], uint8_t *dst, uint32_t g,
+template <int QB, int NC, int NP, int S, int... B>
+__device__ __forceinline__ void emit_unit_group(const UnitBits<QB, NC, NP> &ub, uint8_t *dst, uint32_t g,
                                                 std::integer_sequence<int, B...>)
 {
-    ((dst[(uint32_t)B * g] = (uint8_t)((axis_index<QB, S, B>(h, 0) << 3) |
-                                       (QB == 1 ? 0u : axis_index<QB, S, B>(h, QB == 1 ? 0 : 1)))), ...);
+    using bits = std::make_integer_sequence<int, S>;
+    ((dst[(uint32_t)B * g] = (uint8_t)((axis_index<QB, NC, NP, S, B, 0>(ub, bits{}) << 3) |
+                                       (QB == 1 ? 0u : axis_index<QB, NC, NP, S, B, (QB == 1 ? 0 : 1)>(ub, bits{})))), ...);
 }
 
 // LDS areas of one pass of the bit chain (rows = OFDM symbols): staged frame words, coded words,
@@ -495,9 +548,10 @@ struct QamWalks {
 };
 
 // Frame bytes -> punctured coded bits of rows row0 .. row0 + rows_here - 1 in B.pun (stride: the coded
-// stride at rate 1/2, else the punctured one).  Called by every thread of the workgroup; starts and
-// ends with a barrier.
-template <int NC, int NP>
+// stride at rate 1/2, else the punctured one).  SPLIT: no interleaving of the encoder's outputs and
+// no puncturing pass -- stream A goes to B.cod, stream B to B.pun, one word per 32 input bits each
+// (for UnitBits).  Called by every thread of the workgroup; starts and ends with a barrier.
+template <int NC, int NP, bool SPLIT>
 __device__ __forceinline__ void qam_rows_to_punctured(const QamTxParams &Q, const uint8_t *__restrict__ data,
                                                       uint64_t row0, uint32_t rows_here, const QamBufs &B,
                                                       const QamWalks &wk, uint32_t in_per_row)
@@ -566,11 +620,16 @@ __device__ __forceinline__ void qam_rows_to_punctured(const QamTxParams &Q, cons
         const uint32_t y4 = __funnelshift_r(cur, prev, 4), y5 = __funnelshift_r(cur, prev, 5);
         const uint32_t y6 = __funnelshift_r(cur, prev, 6);
         const uint32_t aw = cur ^ y3 ^ y4 ^ y5 ^ y6, bw = cur ^ y1 ^ y3 ^ y4 ^ y6;
-        const uint64_t both = (spread_bits(aw) << 1) | spread_bits(bw);     // A before B, MSB first
-        B.cod[w.r * B.cod_stride + 2u * w.x] = (uint32_t)(both >> 32);
-        B.cod[w.r * B.cod_stride + 2u * w.x + 1u] = (uint32_t)both;
+        if constexpr (SPLIT) {
+            B.cod[w.r * B.cod_stride + w.x] = aw;
+            B.pun[w.r * B.pun_stride + w.x] = bw;
+        } else {
+            const uint64_t both = (spread_bits(aw) << 1) | spread_bits(bw);     // A before B, MSB first
+            B.cod[w.r * B.cod_stride + 2u * w.x] = (uint32_t)(both >> 32);
+            B.cod[w.r * B.cod_stride + 2u * w.x + 1u] = (uint32_t)both;
+        }
     }
-    if constexpr (NP != NC) {
+    if constexpr (NP != NC && !SPLIT) {
         __syncthreads();
         // ---- puncturing: 4 words -> 3 (keep 3 of 4) or 3 words -> 2 (keep 4 of 6) per thread
         for (RowWalk w = wk.pun; w.r < rows_here; w.next()) {
@@ -592,24 +651,16 @@ __device__ __forceinline__ void qam_rows_to_punctured(const QamTxParams &Q, cons
     __syncthreads();
 }
 
-// The 16 carriers c', c' + G, .. c' + 15 G of a row (G = ncarriers / 16) from the QB units behind
-// them: one level-index byte per carrier into idx_row (the row's ncarriers bytes).
-template <int QB>
-__device__ __forceinline__ void qam_group_to_idx(const uint32_t *P, uint32_t cprime, uint32_t G, uint8_t *idx_row)
+// The 16 carriers c', c' + G, .. c' + 15 G of a row (G = ncarriers / 16) from the row's two coded
+// streams: one level-index byte per carrier into idx_row (the row's ncarriers bytes).
+template <int QB, int NC, int NP>
+__device__ __forceinline__ void qam_group_to_idx(const uint32_t *SA, const uint32_t *SB, uint32_t cprime, uint32_t G,
+                                                 uint8_t *idx_row)
 {
     constexpr int S = QB / 2 > 1 ? QB / 2 : 1;
-    uint32_t h[QB == 1 ? 1 : QB];                                 // the units of the group, 16 bits each
-    if constexpr (QB == 1) {
-        h[0] = (P[cprime >> 1] >> (16u * (1u - (cprime & 1u)))) & 0xFFFFu;
-    } else {
-#pragma unroll
-        for (int i = 0; i < QB / 2; i++) {
-            const uint32_t v = P[(QB / 2) * cprime + i];
-            h[2 * i] = v >> 16;
-            h[2 * i + 1] = v & 0xFFFFu;
-        }
-    }
-    emit_unit_group<QB, S>(h, idx_row + cprime, G, std::make_integer_sequence<int, 16>{});
+    UnitBits<QB, NC, NP> ub;
+    ub.load(SA, SB, cprime);
+    emit_unit_group<QB, NC, NP, S>(ub, idx_row + cprime, G, std::make_integer_sequence<int, 16>{});
 }
 
 // rawofdm/src/lib/qam/raw_qam.cc:63-74: level of an axis index (first bit = MSB), S bits per axis
@@ -635,9 +686,11 @@ __global__ void __launch_bounds__(256) k_raw_qam_tx_fast(QamTxParams Q, const ui
     extern __shared__ uint32_t s_qam[];
     uint32_t *s_in = s_qam;                                       // frame bytes behind the rows, MSB-first words
     uint32_t *s_cod = s_in + in_stride * rows_per_iter;           // coded bits of the rows, MSB first
-    uint32_t *s_pun = NP == NC ? s_cod : s_cod + cod_stride * rows_per_iter;
-    const uint32_t p_stride = NP == NC ? cod_stride : pun_stride;
-    uint32_t *s_row = s_cod + cod_stride * rows_per_iter + (NP == NC ? 0u : pun_stride * rows_per_iter);   // 4 words per row
+    // (GROUPED: s_cod / s_pun hold the encoder's streams A / B, always two areas)
+    constexpr bool ONE_AREA = NP == NC && !GROUPED;
+    uint32_t *s_pun = ONE_AREA ? s_cod : s_cod + cod_stride * rows_per_iter;
+    const uint32_t p_stride = ONE_AREA ? cod_stride : pun_stride;
+    uint32_t *s_row = s_cod + cod_stride * rows_per_iter + (ONE_AREA ? 0u : pun_stride * rows_per_iter);   // 4 words per row
     uint16_t *s_g = reinterpret_cast<uint16_t *>(s_row + 4u * rows_per_iter);
     // GROUPED: no group table; the level indices of the pass, one byte per carrier value
     uint8_t *s_idx = reinterpret_cast<uint8_t *>(s_row + 4u * rows_per_iter);
@@ -662,13 +715,14 @@ __global__ void __launch_bounds__(256) k_raw_qam_tx_fast(QamTxParams Q, const ui
     const QamBufs bufs = {s_in, s_cod, s_pun, s_row, in_stride, cod_stride, pun_stride};
     for (uint64_t row0 = (uint64_t)blockIdx.x * rows_per_iter; row0 < n_rows; row0 += (uint64_t)gridDim.x * rows_per_iter) {
         const uint32_t rows_here = n_rows - row0 < rows_per_iter ? (uint32_t)(n_rows - row0) : rows_per_iter;
-        qam_rows_to_punctured<NC, NP>(Q, data, row0, rows_here, bufs, walks, in_per_row);
+        qam_rows_to_punctured<NC, NP, GROUPED>(Q, data, row0, rows_here, bufs, walks, in_per_row);
         // ---- interleaver + QAM, one thread per carrier value
         float2 *orow = out + row0 * Q.ncarriers;
         if constexpr (GROUPED) {
             const uint32_t G = Q.ncarriers / 16u;
             for (RowWalk w = walk_car; w.r < rows_here; w.next()) {
-                qam_group_to_idx<QB>(s_pun + w.r * p_stride, w.x, G, s_idx + w.r * Q.ncarriers);
+                qam_group_to_idx<QB, NC, NP>(s_cod + w.r * cod_stride, s_pun + w.r * pun_stride, w.x, G,
+                                             s_idx + w.r * Q.ncarriers);
             }
             __syncthreads();
             // two values per thread: 16-byte stores, consecutive over the workgroup
@@ -728,8 +782,7 @@ k_raw_tx(RawParams R, QamTxParams Q, const uint8_t *__restrict__ data, float2 *_
     // the bit chain's staging lives where the transposition areas will be
     uint32_t *s_in = reinterpret_cast<uint32_t *>(s_t);
     uint32_t *s_cod = s_in + in_stride * rows_pass;
-    uint32_t *s_pun = NP == NC ? s_cod : s_cod + cod_stride * rows_pass;
-    const uint32_t p_stride = NP == NC ? cod_stride : pun_stride;
+    uint32_t *s_pun = s_cod + cod_stride * rows_pass;             // s_cod / s_pun: the encoder's streams A / B
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < N; i += 64 * W) {
@@ -756,9 +809,10 @@ k_raw_tx(RawParams R, QamTxParams Q, const uint8_t *__restrict__ data, float2 *_
     for (uint32_t row0 = blockIdx.x * rows_pass; row0 < n_rows; row0 += gridDim.x * rows_pass) {
         const uint32_t rows_here = n_rows - row0 < rows_pass ? n_rows - row0 : rows_pass;
         // ---- bit chain (its first barrier also closes the previous pass)
-        qam_rows_to_punctured<NC, NP>(Q, data, row0, rows_here, bufs, walks, in_per_row);
+        qam_rows_to_punctured<NC, NP, true>(Q, data, row0, rows_here, bufs, walks, in_per_row);
         for (RowWalk w = walk_car; w.r < rows_here; w.next())
-            qam_group_to_idx<QB>(s_pun + w.r * p_stride, w.x, G, s_idx + w.r * Q.ncarriers);
+            qam_group_to_idx<QB, NC, NP>(s_cod + w.r * cod_stride, s_pun + w.r * pun_stride, w.x, G,
+                                         s_idx + w.r * Q.ncarriers);
         __syncthreads();                                          // index bytes complete, staging dead
 
         // ---- modulator, SPW symbols per wave and round (the waves run their rounds independently)
@@ -930,8 +984,8 @@ static int launch_raw_tx(const ofdmtx_ctx *ctx, const RawParams &rp, const QamTx
     constexpr int N = L * M, S = L > M ? L : M, SPW = 64 / S, ROWS = W * SPW, TT = M * (L + 1);
     const int TS = ((TT > (int)(rp.n + rp.cp) ? TT : (int)(rp.n + rp.cp)) + 1) & ~1;
     const uint32_t cod_bits = Q.cbps / Q.np * Q.nc;
-    const uint32_t cod_stride = ((cod_bits + 63u) / 64u) * 2u + 4u;
-    const uint32_t pun_stride = Q.nc == Q.np ? 0u : Q.nc == 4 ? 3u * ((cod_bits + 127u) / 128u) : 2u * ((cod_bits + 95u) / 96u);
+    // the two encoder streams, one word per 32 input bits each, plus the word a 12-bit window may reach into
+    const uint32_t cod_stride = (cod_bits + 63u) / 64u + 1u, pun_stride = cod_stride;
     const uint32_t in_stride = (cod_bits / 2u + 31u) / 32u + 4u;
     // rows per pass of the bit chain: rounds of ROWS rows, about 4096 carrier values, and its staging
     // must fit into the transposition areas it borrows
@@ -1130,14 +1184,19 @@ int ofdmtx_raw_qam_tx(ofdmtx_ctx *ctx, int qambits, int nc, int np, uint32_t nca
     hipStream_t st = (hipStream_t)stream;
     float2 *o2 = reinterpret_cast<float2 *>(d_out);
     // table entries of raw_qam.py:19-28: the structured kernel (see k_raw_qam_tx_fast)
-    const uint32_t cod_stride = cod_words + 4u;                   // the puncturing pass reads whole units
     const uint32_t cod_bits = Q.cbps / (uint32_t)np * (uint32_t)nc;
-    const uint32_t pun_stride = nc == np ? 0u : nc == 4 ? 3u * ((cod_bits + 127u) / 128u) : 2u * ((cod_bits + 95u) / 96u);
+    // rows per pass: the grouped form keeps one thread per 16 carriers busy, so it wants 16x the rows
+    const bool grouped = ncarriers % 16u == 0 && ((uintptr_t)d_out & 15u) == 0;      // it stores 16 bytes at a time
+    // per-carrier form: interleaved coded words (the puncturing pass reads whole units) and punctured
+    // words; grouped form: the two encoder streams, one word per 32 input bits each, plus the word
+    // a 12-bit window may reach into
+    const uint32_t stream_words = (cod_bits + 63u) / 64u + 1u;
+    const uint32_t cod_stride = grouped ? stream_words : cod_words + 4u;
+    const uint32_t pun_stride = grouped ? stream_words
+                                        : nc == np ? 0u : nc == 4 ? 3u * ((cod_bits + 127u) / 128u) : 2u * ((cod_bits + 95u) / 96u);
     // staged input per row: 4 bytes ahead of the row's first input bit, the row's input bits, slack
     // for a bit offset and the word read past the end
     const uint32_t in_stride = (cod_bits / 2u + 31u) / 32u + 4u;
-    // rows per pass: the grouped form keeps one thread per 16 carriers busy, so it wants 16x the rows
-    const bool grouped = ncarriers % 16u == 0 && ((uintptr_t)d_out & 15u) == 0;      // it stores 16 bytes at a time
     const uint32_t row_words = in_stride + cod_stride + pun_stride + 4u;
     uint32_t rows_fast = grouped ? (4096u + ncarriers - 1u) / ncarriers : rows_per_iter;
     // behind the rows: the group table (cbps / s entries), or in the grouped form one byte per value
