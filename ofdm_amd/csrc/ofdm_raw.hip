@@ -448,6 +448,7 @@ __device__ __forceinline__ uint32_t keep_4_of_6(uint32_t c)      // 24 bits (rig
 // divides col.  A group of s bits is one axis of one carrier (raw_qam.cc:63-74: I, then Q), so a
 // carrier's axis reads s neighbouring units at ONE bit position: s 16-bit LDS reads and a shift
 // each, against a table look-up, two divisions and a word read per bit in the general kernel.
+
 // Walks idx = tid, tid + 256, .. as (row, column) pairs of rows `width` wide without dividing
 // inside the loop.
 struct RowWalk {
