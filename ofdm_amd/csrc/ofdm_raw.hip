@@ -1262,8 +1262,10 @@ int ofdmtx_raw_tx(ofdmtx_ctx *ctx, const ofdmtx_raw_plan *pl, int qambits, int n
     float2 *iq = reinterpret_cast<float2 *>(d_iq);
     hipStream_t st = (hipStream_t)stream;
     switch (rp.n) {
-    case 64: return launch_raw_tx<8, 8, 4>(ctx, rp, Q, key, d_bytes, iq, st);
-    case 128: return launch_raw_tx<8, 16, 4>(ctx, rp, Q, key, d_bytes, iq, st);
+    // waves per workgroup as measured: two for the short symbols (0.34 against 0.39 ms at N=64, 0.61
+    // against 0.72 ms at N=128, 64-QAM, 2.6e5 symbols; one and eight are slower), four for the long ones
+    case 64: return launch_raw_tx<8, 8, 2>(ctx, rp, Q, key, d_bytes, iq, st);
+    case 128: return launch_raw_tx<8, 16, 2>(ctx, rp, Q, key, d_bytes, iq, st);
     case 256: return launch_raw_tx<16, 16, 4>(ctx, rp, Q, key, d_bytes, iq, st);
     case 512: return launch_raw_tx<16, 32, 4>(ctx, rp, Q, key, d_bytes, iq, st);
     // N = 1024: the 10 KB areas per symbol leave 4 waves per CU, too few for the bit chain's phases;
