@@ -1263,7 +1263,7 @@ int ofdmtx_raw_tx(ofdmtx_ctx *ctx, const ofdmtx_raw_plan *pl, int qambits, int n
     hipStream_t st = (hipStream_t)stream;
     switch (rp.n) {
     // waves per workgroup as measured: two for the short symbols (0.34 against 0.39 ms at N=64, 0.61
-    // against 0.72 ms at N=128, 64-QAM, 2.6e5 symbols; one and eight are slower), four for the long ones
+    // against 0.72 ms at N=128, 64-QAM, 1.05e6 symbols; one and eight are slower), four for the long ones
     case 64: return launch_raw_tx<8, 8, 2>(ctx, rp, Q, key, d_bytes, iq, st);
     case 128: return launch_raw_tx<8, 16, 2>(ctx, rp, Q, key, d_bytes, iq, st);
     case 256: return launch_raw_tx<16, 16, 4>(ctx, rp, Q, key, d_bytes, iq, st);
