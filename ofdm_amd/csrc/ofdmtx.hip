@@ -683,14 +683,41 @@ k_encode_bits(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads,
 constexpr int TG = 72;   // float2 per symbol in the transposition layout (8 rows x 9)
 constexpr int RS = 88;   // float2 per row in the staging layout
 
+// IQ stores.  A wave addresses its packet's rows through a buffer resource over the packet (base in
+// SGPRs, 32-bit byte offsets per lane), which is also the way to give the stores a cache policy the
+// compiler knows about: IQ_STORE_AUX is the instruction's policy field, 16 = sc1.  The samples are
+// written once and never read back by this kernel; with sc1 the payload reads issued beside them
+// cost measurably less (48 GB of such stores next to 1.5 GB of reads: 9.60 against 9.75 ms), the
+// stores themselves run at the same rate.
+#ifndef IQ_STORE_AUX
+#define IQ_STORE_AUX 16
+#endif
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t iq_window(const void *base)
+{
+    const uint64_t a = reinterpret_cast<uint64_t>(base);          // the same in every lane of the wave
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
+    // raw buffer (stride 0): offsets are checked against the record count, which is left wide open --
+    // the host has sized the IQ buffer for every row of the plan
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uint64_t)hi << 32) | lo), 0, 0x7FFFFFFF, 0x00020000);
+}
+// float4 number `idx` of the window
+__device__ __forceinline__ void iq_store(__amdgpu_buffer_rsrc_t w, uint32_t idx, float4 v)
+{
+    const u32x4 d = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(d, w, (int)(idx * 16u), 0, IQ_STORE_AUX);
+}
+
 // A group of up to 8 consecutive OFDM symbol rows by one wavefront, 8 lanes per row
 // (lane = 8*g + l): 64-point inverse DFT -> cyclic prefix -> coalesced stores.
 //   active  the lane's row exists
 //   x       (active) the lane's decimated carriers X[l + 8m], m = 0..7
-//   buf     the wave's LDS area of 8*RS float2; dst = first of the group's `rows_here` rows
+//   buf     the wave's LDS area of 8*RS float2; dst = float4 number, in the packet's window `win`,
+//           of the first of the group's `rows_here` rows
 __device__ __forceinline__ void ifft64_emit(bool active, v2f (&x)[8], int l, int g, int lane, v2f *buf,
-                                            const v2f *s_tw, bool swap_iq, float4 *__restrict__ dst,
-                                            uint32_t rows_here)
+                                            const v2f *s_tw, bool swap_iq, __amdgpu_buffer_rsrc_t win,
+                                            uint32_t dst, uint32_t rows_here)
 {
     SEC("fft1");
     // ---- 64-point inverse DFT as 8 x 8: x[8q+p] = sum_l W8^{lq} W64^{lp} sum_m X[l+8m] W8^{mp}
@@ -734,14 +761,14 @@ __device__ __forceinline__ void ifft64_emit(bool active, v2f (&x)[8], int l, int
 #pragma unroll
         for (int i = 0; i < 5; i++) {
             const int e = i * 64 + lane;              // float4 index, 40 per row
-            dst[e] = *reinterpret_cast<const float4 *>(buf + (e / 40) * RS + (e % 40) * 2);
+            iq_store(win, dst + (uint32_t)e, *reinterpret_cast<const float4 *>(buf + (e / 40) * RS + (e % 40) * 2));
         }
     } else {
 #pragma unroll
         for (int i = 0; i < 5; i++) {
             const int e = i * 64 + lane;
             if ((uint32_t)e < rows_here * 40u)
-                dst[e] = *reinterpret_cast<const float4 *>(buf + (e / 40) * RS + (e % 40) * 2);
+                iq_store(win, dst + (uint32_t)e, *reinterpret_cast<const float4 *>(buf + (e / 40) * RS + (e % 40) * 2));
         }
     }
 }
@@ -889,7 +916,7 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ in, float2 *__restri
         const Pkt k = load_pkt<UNIFORM>(P, p);
         const RegimeInfo ri = regime_info(REGIME ? REGIME : (int)k.regime);
         const size_t row0 = UNIFORM ? (size_t)p * P.rows_per_pkt : (size_t)P.row_start[p];
-        float4 *out = reinterpret_cast<float4 *>(iq + row0 * SYM_LEN);
+        const __amdgpu_buffer_rsrc_t win = iq_window(iq + row0 * SYM_LEN);     // the packet's rows
         const uint32_t sym_rows = k.n_sym + 1u;                    // SIGNAL + DATA symbols
 
         if constexpr (FROM_MSG) {
@@ -917,16 +944,15 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ in, float2 *__restri
         // ---- preamble rows (ftw/ftw_ofdm_preamble.cc:79-95) and zero gap (ftw/ftw_zerogap.cc:88-99)
         if (pre_rows) {
             const float4 *pre4 = reinterpret_cast<const float4 *>(s_pre);
-            for (uint32_t i = lane; i < PRE_ROWS * SYM_LEN / 2; i += 64) out[i] = pre4[i];
+            for (uint32_t i = lane; i < PRE_ROWS * SYM_LEN / 2; i += 64) iq_store(win, i, pre4[i]);
             if constexpr (PNC)
                 if (pre_rows > (uint32_t)PRE_ROWS)        // PNC roles: two more rows
-                    for (uint32_t i = PRE_ROWS * SYM_LEN / 2 + lane; i < PNC_PRE_ROWS * SYM_LEN / 2; i += 64) out[i] = pre4[i];
+                    for (uint32_t i = PRE_ROWS * SYM_LEN / 2 + lane; i < PNC_PRE_ROWS * SYM_LEN / 2; i += 64) iq_store(win, i, pre4[i]);
         }
         if (gap_rows) {
-            float4 *gp = out + (size_t)(pre_rows + sym_rows) * (SYM_LEN / 2);
-            for (uint32_t i = lane; i < GAP_ROWS * SYM_LEN / 2; i += 64) gp[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const uint32_t gp = (pre_rows + sym_rows) * (SYM_LEN / 2);
+            for (uint32_t i = lane; i < GAP_ROWS * SYM_LEN / 2; i += 64) iq_store(win, gp + i, make_float4(0.f, 0.f, 0.f, 0.f));
         }
-        out += (size_t)pre_rows * (SYM_LEN / 2);
 
         // chunks of up to 64 DATA symbols (one per lane); the first chunk also carries the SIGNAL
         // symbol, in slot row 0, so its DATA rows sit one row further down
@@ -1023,8 +1049,8 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ in, float2 *__restri
                         }
                     }
                 }
-                ifft64_emit(active, x, l, g, lane_r, buf, reinterpret_cast<const v2f *>(s_tw), swap_iq,
-                            out + (size_t)(row_base + r0) * (SYM_LEN / 2),
+                ifft64_emit(active, x, l, g, lane_r, buf, reinterpret_cast<const v2f *>(s_tw), swap_iq, win,
+                            (pre_rows + row_base + r0) * (SYM_LEN / 2),
                             rows_chunk - r0 < 8u ? rows_chunk - r0 : 8u);
                 SEC("end");
                 wave_sync();
