@@ -104,4 +104,31 @@ __device__ __forceinline__ void idft8(v2f (&x)[8])
     x[3] = __builtin_elementwise_fma(-h, t7, b3); x[7] = __builtin_elementwise_fma(h, t7, b3);
 }
 
+// IQ stores.  A wave addresses a run of output rows through a buffer resource (base in
+// SGPRs, 32-bit byte offsets per lane), which is also the way to give the stores a cache policy the
+// compiler knows about: IQ_STORE_AUX is the instruction's policy field, 16 = sc1.  The samples are
+// written once and never read back by this kernel; with sc1 the payload reads issued beside them
+// cost measurably less (48 GB of such stores next to 1.5 GB of reads: 9.60 against 9.75 ms), the
+// stores themselves run at the same rate.
+#ifndef IQ_STORE_AUX
+#define IQ_STORE_AUX 16
+#endif
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t iq_window(const void *base)
+{
+    const uint64_t a = reinterpret_cast<uint64_t>(base);          // the same in every lane of the wave
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
+    // raw buffer (stride 0): offsets are checked against the record count, which is left wide open --
+    // the host has sized the IQ buffer for every row of the plan
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uint64_t)hi << 32) | lo), 0, 0x7FFFFFFF, 0x00020000);
+}
+// float4 number `idx` of the window
+template <int AUX = IQ_STORE_AUX>
+__device__ __forceinline__ void iq_store(__amdgpu_buffer_rsrc_t w, uint32_t idx, float4 v)
+{
+    const u32x4 d = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(d, w, (int)(idx * 16u), 0, AUX);
+}
+
 #endif

@@ -103,6 +103,10 @@ constexpr int bit_reverse(int i, int n)
 }
 
 constexpr int RAW_WAVES = 4;
+// Store policy of the modulator's output rows: plain.  These kernels read 0.6 bytes per byte written (the
+// 802.11a kernel 0.03), and with sc1 on the stores they are slower, not faster (N=256: 1.00 against 0.97 ms,
+// N=1024: 1.07 against 0.97 ms per 1.05e6 / 2.6e5 symbols); the bit chain's value stores keep sc1 (2-3 % faster).
+constexpr int RAW_ROW_AUX = 0;
 
 // Steps 1b-3 of the N = L * M point modulator for the S = max(L, M) lanes of one symbol (lane t of
 // the symbol, symbol area T, wave's first area T_wave with SPW areas of TS float2 each):
@@ -153,8 +157,8 @@ __device__ __forceinline__ void raw_transform_store(bool active, int t, int lane
         float2 *o = iq + (size_t)row_s * row_len;
         if ((row_len & 1u) == 0u) {
             const float4 *src4 = reinterpret_cast<const float4 *>(Ts);
-            float4 *dst4 = reinterpret_cast<float4 *>(o);
-            for (uint32_t i = lane; i < row_len / 2; i += 64) dst4[i] = src4[i];
+            const __amdgpu_buffer_rsrc_t win = iq_window(o);
+            for (uint32_t i = lane; i < row_len / 2; i += 64) iq_store<RAW_ROW_AUX>(win, i, src4[i]);
         } else {
             for (uint32_t i = lane; i < row_len; i += 64) o[i] = make_float2(Ts[i].x, Ts[i].y);
         }
@@ -204,8 +208,8 @@ k_raw_modulate(RawParams R, const float2 *__restrict__ data, float2 *__restrict_
             const uint32_t cnt = R.n_pre * row_len;
             if ((row_len & 1u) == 0u) {
                 const float4 *src4 = reinterpret_cast<const float4 *>(R.pre_rows);
-                float4 *dst4 = reinterpret_cast<float4 *>(iq + row * row_len);
-                for (uint32_t i = lane; i < cnt / 2; i += 64) dst4[i] = src4[i];
+                const __amdgpu_buffer_rsrc_t win = iq_window(iq + row * row_len);
+                for (uint32_t i = lane; i < cnt / 2; i += 64) iq_store<RAW_ROW_AUX>(win, i, src4[i]);
             } else {
                 float2 *dst = iq + row * row_len;
                 for (uint32_t i = lane; i < cnt; i += 64) dst[i] = R.pre_rows[i];
@@ -728,10 +732,11 @@ __global__ void __launch_bounds__(256) k_raw_qam_tx_fast(QamTxParams Q, const ui
             __syncthreads();
             // two values per thread: 16-byte stores, consecutive over the workgroup
             const uint32_t n_val = rows_here * Q.ncarriers;       // even: ncarriers is a multiple of 16
+            const __amdgpu_buffer_rsrc_t win = iq_window(orow);
             for (uint32_t i = 2u * threadIdx.x; i < n_val; i += 2u * blockDim.x) {
                 const uint32_t v = *reinterpret_cast<const uint16_t *>(s_idx + i), v0 = v & 0xFFu, v1 = v >> 8;
-                *reinterpret_cast<float4 *>(orow + i) =
-                    make_float4(s_lv[v0 >> 3], QB == 1 ? 0.f : s_lv[v0 & 7u], s_lv[v1 >> 3], QB == 1 ? 0.f : s_lv[v1 & 7u]);
+                iq_store(win, i / 2u, make_float4(s_lv[v0 >> 3], QB == 1 ? 0.f : s_lv[v0 & 7u], s_lv[v1 >> 3],
+                                                              QB == 1 ? 0.f : s_lv[v1 & 7u]));
             }
         } else
         for (RowWalk w = walk_car; w.r < rows_here; w.next()) {
@@ -845,8 +850,8 @@ k_raw_tx(RawParams R, QamTxParams Q, const uint8_t *__restrict__ data, float2 *_
             const uint32_t cnt = R.n_pre * row_len;
             if ((row_len & 1u) == 0u) {
                 const float4 *src4 = reinterpret_cast<const float4 *>(R.pre_rows);
-                float4 *dst4 = reinterpret_cast<float4 *>(iq + frow * row_len);
-                for (uint32_t i = lane; i < cnt / 2; i += 64) dst4[i] = src4[i];
+                const __amdgpu_buffer_rsrc_t win = iq_window(iq + frow * row_len);
+                for (uint32_t i = lane; i < cnt / 2; i += 64) iq_store<RAW_ROW_AUX>(win, i, src4[i]);
             } else {
                 float2 *dst = iq + frow * row_len;
                 for (uint32_t i = lane; i < cnt; i += 64) dst[i] = R.pre_rows[i];
