@@ -83,8 +83,8 @@ def load_traffic(workload_key):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--packets", type=int, default=1_000_000, help="packets per GPU per step")
     ap.add_argument("--fused", type=int, default=1, help="1: single fused kernel (ofdmtx_tx), 0: two kernels")
     ap.add_argument("--stage-steps", type=int, default=3, help="untimed extra passes of the two-kernel path")
