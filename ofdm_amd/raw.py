@@ -185,6 +185,7 @@ class ofdm_mod(object):
         self.ctx = ctx if ctx is not None else TxContext(device)
         self._log = bool(getattr(options, "log", False))
         self.fused = False          # whether the last modulate_bytes ran as one kernel
+        self._frame_plans = {}      # (n_frames, frame_size) -> RawPlan; a plan uploads tables and transforms the preambles
 
     def _finish(self, plan, data):
         if self._log:                                               # raw_ofdm_mod.py:54-57 ("tx-map.dat")
@@ -192,6 +193,18 @@ class ofdm_mod(object):
             mapped.cpu().numpy().tofile("tx-map.dat")
             return iq
         return plan.modulate(data)
+
+    def _plan_frames(self, n_frames, frame_size):
+        """Plans for back-to-back frames are kept: a stream of equal batches builds its plan once."""
+        key = (int(n_frames), int(frame_size))
+        plan = self._frame_plans.get(key)
+        if plan is None:
+            p = self.params
+            if len(self._frame_plans) >= 8:
+                self._frame_plans.pop(next(iter(self._frame_plans)))
+            plan = plan_frames(self.ctx, p.fft_length, p.cp_length, p.padded_carriers, p.padded_preambles, *key)
+            self._frame_plans[key] = plan
+        return plan
 
     def _as_device(self, data):
         if not torch.is_tensor(data):
@@ -210,9 +223,7 @@ class ofdm_mod(object):
         n_sym = data.numel() // p.data_tones
         if n_sym % frame_size:
             raise ValueError("data does not hold whole frames")
-        plan = plan_frames(self.ctx, p.fft_length, p.cp_length, p.padded_carriers, p.padded_preambles,
-                           n_sym // frame_size, frame_size)
-        return self._finish(plan, data)
+        return self._finish(self._plan_frames(n_sym // frame_size, frame_size), data)
 
     def modulate_bytes(self, bitrate, data, nsymbols, out=None):
         """qam_tx(bitrate, data_tones, nsymbols) feeding modulate_frames (rawofdm/examples/
@@ -228,7 +239,7 @@ class ofdm_mod(object):
         if data.dtype != torch.uint8 or data.numel() % tx.framebytes:
             raise ValueError("data must be uint8 and hold whole frames of %d bytes" % tx.framebytes)
         n_frames = data.numel() // tx.framebytes
-        plan = plan_frames(self.ctx, p.fft_length, p.cp_length, p.padded_carriers, p.padded_preambles, n_frames, nsymbols)
+        plan = self._plan_frames(n_frames, nsymbols)
         iq = out if out is not None else torch.empty(plan.n_samples, dtype=torch.complex64, device=dev)
         if iq.numel() < plan.n_samples or iq.dtype != torch.complex64:
             raise ValueError("iq buffer must be complex64 with >= %d samples" % plan.n_samples)
