@@ -73,3 +73,44 @@ def test_two_rank_gather_equals_single_stream():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert np.array_equal(got, want)
+
+
+def _raw_worker(rank, world, port, data, size, q):
+    """rawofdm: frames are independent (no state runs from one frame to the next), so a batch is
+    sharded by frame index exactly like packets."""
+    from oracle import raw_oracle as ro
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        params = ro.OfdmParams(ro.Options(fft_length=64, occupied_tones=52, cp_length=16))
+        n_frames = data.shape[0] // size
+        lo, hi = od.shard_bounds(n_frames, world, rank)
+        rows = ro.modulate(params, data[lo * size:hi * size], ro.frame_flags(hi - lo, size)) if hi > lo else np.zeros((0, 80))
+        mine = torch.from_numpy(np.asarray(rows).astype(np.complex64).reshape(-1))
+        got = od.gather_iq(mine, dst=0)
+        if rank == 0:
+            q.put(got.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_rawofdm_frames_equal_single_stream():
+    from oracle import raw_oracle as ro
+    params = ro.OfdmParams(ro.Options(fft_length=64, occupied_tones=52, cp_length=16))
+    rng = np.random.default_rng(5)
+    size, n_frames = 4, 5
+    data = ((rng.integers(0, 2, (n_frames * size, params.data_tones)) * 2 - 1) +
+            1j * (rng.integers(0, 2, (n_frames * size, params.data_tones)) * 2 - 1)) / np.sqrt(2)
+    want = np.asarray(ro.modulate(params, data, ro.frame_flags(n_frames, size))).astype(np.complex64).reshape(-1)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_raw_worker, args=(r, 2, port, data, size, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.array_equal(got, want)
