@@ -2,6 +2,7 @@
 """Headline benchmark: 802.11a 54 Mbps, 1500-byte packets, payload -> full PPDU IQ.
 
     python bench.py --gpus N --steps K --warmup W [--packets P]
+    python bench.py --workload rawofdm [--raw-n 1024 --raw-cp 256 --raw-symbols 262144]   (secondary)
 
 One "step" is one pass of the transmit chain over one batch of P synthetic packets per GPU,
 payloads already resident in HBM: by default the fused kernel k_tx (payload -> IQ, the mapper
@@ -80,6 +81,76 @@ def load_traffic(workload_key):
         return None
 
 
+def timed_steps(step, a, dist, backend, dev):
+    """W untimed steps, then K timed ones between barriers; returns (seconds, max over ranks; events)."""
+    for _ in range(a.warmup):
+        step()
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(a.steps)]
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(evs[i])          # events ride on the stream the kernels are launched on
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, evs
+
+
+def run_rawofdm(a, ctx, dev, world, rank, dist, backend):
+    """Config 4: rawofdm's variable-size modulator (carrier values -> IQ), frames sharded by index."""
+    from ofdm_amd import raw
+
+    class O(object):
+        num_preambles, half_sync, verbose, log = 2, True, False, False
+    o = O()
+    o.fft_length, o.occupied_tones, o.cp_length = a.raw_n, int(0.8125 * a.raw_n), a.raw_cp
+    p = raw.ofdm_params(o)
+    size = 16
+    n_frames = a.raw_symbols // size
+    plan = raw.plan_frames(ctx, p.fft_length, p.cp_length, p.padded_carriers, p.padded_preambles, n_frames, size)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(4 + rank)
+    ph = torch.randint(0, 4, (n_frames * size * p.data_tones,), device=dev, generator=gen)
+    data = torch.polar(torch.ones_like(ph, dtype=torch.float32), (2 * ph + 1) * (np.pi / 4)).contiguous()   # unit QPSK
+    iq = torch.empty(plan.n_samples, dtype=torch.complex64, device=dev)
+
+    def step(events=None):
+        if events is not None:
+            events[0].record()
+        plan.modulate(data, out=iq)
+        if events is not None:
+            events[1].record()
+            events[2].record()
+
+    dt, evs = timed_steps(step, a, dist, backend, dev)
+    if rank == 0:
+        kernel_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
+        alg_bytes = data.numel() * 8 + plan.n_samples * 8          # carrier values read + rows written
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        print(json.dumps({
+            "metric": "baseband IQ Msamples/s (node), rawofdm N=%d cp=%d" % (a.raw_n, a.raw_cp),
+            "value": world * plan.n_samples * a.steps / dt / 1e6, "unit": "Msamples/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "rawofdm modulator N=%d cp=%d, %d occupied tones (%d data), %d frames of %d data symbols "
+                                   "+ %d preamble symbols per GPU, unit QPSK values -> IQ"
+                                   % (a.raw_n, a.raw_cp, o.occupied_tones, p.data_tones, n_frames, size, plan.n_pre),
+                       "parallelism": "frames sharded by index over %d GPU(s), no collective" % world},
+            "kernel_ms": {"k_raw_modulate": kernel_ms},
+            "roofline": {"bound": "hbm", "kernel": "k_raw_modulate", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -89,6 +160,11 @@ def main():
     ap.add_argument("--fused", type=int, default=1, help="1: single fused kernel (ofdmtx_tx), 0: two kernels")
     ap.add_argument("--stage-steps", type=int, default=3, help="untimed extra passes of the two-kernel path")
     ap.add_argument("--cpu-sample", type=int, default=100_000, help="packets timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--workload", choices=["ftw", "rawofdm"], default="ftw",
+                    help="ftw: the headline (802.11a 54 Mbit/s packets); rawofdm: the variable-size modulator")
+    ap.add_argument("--raw-n", type=int, default=256)
+    ap.add_argument("--raw-cp", type=int, default=64)
+    ap.add_argument("--raw-symbols", type=int, default=1 << 20, help="data symbols per GPU per step (rawofdm)")
     ap.add_argument("--gather", type=int, default=0,
                     help="1: every step also collects all shards' IQ on rank 0 (RCCL send/recv); size --packets so "
                          "that N shards fit one GPU")
@@ -114,6 +190,11 @@ def main():
     torch.cuda.set_device(dev)
 
     ctx = TxContext(local)
+    if a.workload == "rawofdm":
+        run_rawofdm(a, ctx, dev, world, rank, dist, backend)
+        if dist:
+            dist.destroy_process_group()
+        return
     n = a.packets
     info = _lib.packet_info(REGIME, PAYLOAD)
     # packets are sharded by index: rank r holds packets [r*n, (r+1)*n); the stream-wide pilot
@@ -146,25 +227,7 @@ def main():
             from ofdm_amd.dist import gather_iq
             gather_iq(iq, dst=0)
 
-    for _ in range(a.warmup):
-        step()
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(a.steps)]
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(evs[i])          # events ride on the stream the kernels are launched on
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, evs = timed_steps(step, a, dist, backend, dev)
 
     first_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
     second_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))
