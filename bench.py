@@ -3,6 +3,7 @@
 
     python bench.py --gpus N --steps K --warmup W [--packets P]
     python bench.py --workload rawofdm [--raw-n 1024 --raw-cp 256 --raw-symbols 262144]   (secondary)
+    python bench.py --workload ragged [--ragged-packets 400000]                            (secondary)
 
 One "step" is one pass of the transmit chain over one batch of P synthetic packets per GPU,
 payloads already resident in HBM: by default the fused kernel k_tx (payload -> IQ, the mapper
@@ -151,6 +152,59 @@ def run_rawofdm(a, ctx, dev, world, rank, dist, backend):
                          "algorithmic_bytes_per_launch": alg_bytes}}), flush=True)
 
 
+def run_ragged(a, ctx, dev, world, rank, dist, backend):
+    """Config 3: mixed-rate ragged batch (all eight rates, payloads of 1..2304 bytes), packet ranges per rank."""
+    n = a.ragged_packets
+    n_dbps = np.array([0, 24, 36, 48, 72, 96, 144, 192, 216])
+
+    def shard(r):
+        rng = np.random.default_rng([3, r])
+        return rng.integers(1, 9, n).astype(np.uint8), rng.integers(1, 2305, n).astype(np.uint32)
+
+    # the stream-wide pilot counter runs on over the shards in front of this one (SIGNAL + DATA symbols each)
+    symbols_before = 0
+    for r in range(rank):
+        rg, ln = shard(r)
+        bits = 16 + 8 * (ln.astype(np.int64) + 28) + 6
+        symbols_before += int(((bits + n_dbps[rg] - 1) // n_dbps[rg] + 1).sum())
+    regimes, lens = shard(rank)
+    plan = ctx.plan_ragged(regimes, lens, pilot_start=symbols_before % 127)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(3 + rank)
+    payloads = torch.randint(0, 256, (int(lens.sum()),), dtype=torch.uint8, device=dev, generator=gen)
+    iq = plan.alloc_iq()
+
+    def step(events=None):
+        if events is not None:
+            events[0].record()
+        plan.tx(payloads, out=iq)
+        if events is not None:
+            events[1].record()
+            events[2].record()
+
+    dt, evs = timed_steps(step, a, dist, backend, dev)
+    samples = torch.tensor([plan.n_samples], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    if dist:
+        dist.all_reduce(samples)                       # shards differ in size: the job's samples per step
+    if rank == 0:
+        kernel_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
+        alg_bytes = int(lens.sum()) + plan.n_samples * 8            # payloads read + rows written (rank 0's shard)
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        print(json.dumps({
+            "metric": "baseband IQ Msamples/s (node), 802.11a mixed-rate ragged batch",
+            "value": float(samples.item()) * a.steps / dt / 1e6, "unit": "Msamples/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "802.11a, all eight rates, payloads of 1..2304 bytes, %d packets per GPU, payload -> "
+                                   "full PPDU IQ" % n,
+                       "packets_per_gpu": n,
+                       "parallelism": "packet ranges per rank over %d GPU(s), pilot counter continued, no collective" % world},
+            "kernel_ms": {"k_tx": kernel_ms},
+            "roofline": {"bound": "hbm", "kernel": "k_tx (ragged)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -160,8 +214,10 @@ def main():
     ap.add_argument("--fused", type=int, default=1, help="1: single fused kernel (ofdmtx_tx), 0: two kernels")
     ap.add_argument("--stage-steps", type=int, default=3, help="untimed extra passes of the two-kernel path")
     ap.add_argument("--cpu-sample", type=int, default=100_000, help="packets timed on the CPU baseline (0 = skip)")
-    ap.add_argument("--workload", choices=["ftw", "rawofdm"], default="ftw",
-                    help="ftw: the headline (802.11a 54 Mbit/s packets); rawofdm: the variable-size modulator")
+    ap.add_argument("--workload", choices=["ftw", "ragged", "rawofdm"], default="ftw",
+                    help="ftw: the headline (802.11a 54 Mbit/s packets); ragged: mixed rates and lengths; "
+                         "rawofdm: the variable-size modulator")
+    ap.add_argument("--ragged-packets", type=int, default=400_000, help="packets per GPU per step (ragged)")
     ap.add_argument("--raw-n", type=int, default=256)
     ap.add_argument("--raw-cp", type=int, default=64)
     ap.add_argument("--raw-symbols", type=int, default=1 << 20, help="data symbols per GPU per step (rawofdm)")
@@ -190,8 +246,8 @@ def main():
     torch.cuda.set_device(dev)
 
     ctx = TxContext(local)
-    if a.workload == "rawofdm":
-        run_rawofdm(a, ctx, dev, world, rank, dist, backend)
+    if a.workload != "ftw":
+        (run_rawofdm if a.workload == "rawofdm" else run_ragged)(a, ctx, dev, world, rank, dist, backend)
         if dist:
             dist.destroy_process_group()
         return
