@@ -1,0 +1,45 @@
+"""bench.py prints ONE JSON line carrying the keys its callers rely on, for the headline workload and the two
+secondary ones (small batches here; the numbers themselves are not checked)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+        "vs_baseline", "dtype", "data", "config", "roofline"}
+ROOF = {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+
+
+def run_bench(*args):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1"] + list(args),
+                         cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_headline_line():
+    d = run_bench("--packets", "4096", "--cpu-sample", "256")
+    assert KEYS <= set(d) and ROOF <= set(d["roofline"])
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["unit"] == "Msamples/s" and d["value"] > 0 and d["roofline"]["bound"] == "hbm"
+    assert d["config"]["samples_per_packet"] == 6000 and "workload" in d["config"]
+    cb = d["cpu_baseline"]
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(cb) and cb["kind"] == "port" and cb["value"] > 0
+    # the fused kernel and the two-kernel path were both run
+    assert d["kernel_ms"]["k_tx"] > 0 and d["two_kernel_path"]["k_tx_msg_ms"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args", [("--workload", "rawofdm", "--raw-symbols", "8192"),
+                                  ("--workload", "rawofdm", "--raw-n", "1024", "--raw-cp", "128", "--raw-symbols", "4096"),
+                                  ("--workload", "ragged", "--ragged-packets", "3000")], ids=["raw256", "raw1024", "ragged"])
+def test_secondary_lines(args):
+    d = run_bench(*args)
+    assert KEYS <= set(d) and ROOF <= set(d["roofline"])
+    assert d["value"] > 0 and 0 < d["roofline"]["frac"] < 1 and "workload" in d["config"]
