@@ -41,7 +41,9 @@ extern "C" {
 #define OFDMTX_ESHAPE (-6)    /* block parameter the reference's blocks reject with
                                  std::invalid_argument (ftw/ftw_ofdm_pilot_cc.cc:110-111,
                                  ftw/ftw_ofdm_cmap_cc.cc:97-99, ftw/ftw_ofdm_mapper.cc:61-62) */
-#define OFDMTX_ETOOBIG (-7)   /* batch exceeds the 32-bit row index of the kernels          */
+#define OFDMTX_ETOOBIG (-7)   /* batch exceeds the 32-bit row index of the kernels, or the
+                                 fixed capacity of an allocation-free entry point           */
+#define OFDMTX_EBUSY (-8)     /* a ragged plan is still running on another stream          */
 
 /* plan flags */
 #define OFDMTX_F_PREAMBLE 1u  /* prepend the 4x80-sample preamble (ftw/ftw_ofdm_preamble.cc:79-83) */
@@ -106,6 +108,20 @@ int ofdmtx_destroy(ofdmtx_ctx *ctx);
  * uses the fixed BPSK {-1,+1} (ftw/ftw_ofdm_mapper.cc:179,238-240). */
 int ofdmtx_set_constellation(ofdmtx_ctx *ctx, int n_bpsc, const float *re_im, int n);
 
+/* Replace the training table the preamble block emits in front of every packet: the `preamble`
+ * argument of ftw.ofdm_preamble / ftw.pnc_ofdm_preamble (ftw/ftw.i:78-106), of which the blocks
+ * copy the first four rows of symbol_length = 80 samples (ftw/ftw_ofdm_preamble.cc:79-83; the PNC
+ * block takes its rows from the same four, ftw/ftw_pnc_ofdm_preamble.cc:81-103).  re_im: n_samples
+ * complex values (re,im float pairs), host memory; n_samples >= 320 (the reference reads past a
+ * shorter table: OFDMTX_EINVAL here).  The table is scaled by the plan's amplitude like every other
+ * sample.  Takes effect for launches enqueued after the call returns (it synchronises the device). */
+int ofdmtx_set_preamble(ofdmtx_ctx *ctx, const float *re_im, int n_samples);
+/* Replace the row the zero-gap block appends 13 times behind every packet: the `zerogap` argument
+ * of ftw.zerogap / ftw.pnc_zerogap (ftw/ftw.i:110-138), one row of symbol_length = 80 samples
+ * (ftw/ftw_zerogap.cc:88-92).  The reference passes 80 zeros (examples/ftw_packet_utils.py:510).  A
+ * row with non-zero samples is written by a second small kernel behind the fused one. */
+int ofdmtx_set_gap(ofdmtx_ctx *ctx, const float *re_im, int n_samples);
+
 /* ---- host helpers ----------------------------------------------------------------- */
 /* The static tables of examples/ftw_packet_utils.py:497-508 as the device uses them (float32,
  * re/im interleaved): gray_const_bpsk / _qpsk / _qam16 / _qam64 and the 320-sample fft_preamble.
@@ -118,6 +134,10 @@ int ofdmtx_set_constellation(ofdmtx_ctx *ctx, int n_bpsc, const float *re_im, in
 int ofdmtx_get_table(int which, float *out, int n_floats);
 /* ftw.ftw_crc32 (ftw/ftw_crc32.cc:72-82): bit-reversed reflected CRC-32. */
 uint32_t ofdmtx_crc32(const uint8_t *buf, size_t len);
+/* ftw.ftw_update_crc32 (ftw/ftw.i:215-218, ftw/ftw_crc32.cc:33-64): the CRC register after `len`
+ * bytes from the all-ones start value, bit-reversed, without the final inversion.  `crc` is
+ * accepted and ignored, as in the reference (overwritten at ftw/ftw_crc32.cc:53). */
+uint32_t ofdmtx_update_crc32(uint32_t crc, const uint8_t *buf, size_t len);
 /* get_info (examples/ftw_packet_utils.py:25-105) for payload_len bytes behind the 24-byte
  * MAC header.  flags as for plans (they only affect n_rows).  Returns OFDMTX_ELENGTH when the
  * MPDU exceeds what ftw_make accepts (examples/ftw_packet_utils.py:119-121); *out is filled in
@@ -137,8 +157,13 @@ int ofdmtx_plan_uniform(ofdmtx_ctx *ctx, uint64_t n_pkts, int regime, uint32_t p
  * payload in the payload buffer; NULL = densely packed in order) are host arrays.
  * A ragged plan owns device-side work counters from which the waves of ofdmtx_tx /
  * ofdmtx_modulate / ofdmtx_encode_bits draw packets (each kernel leaves them at zero when it
- * ends): the same ragged plan must not run in two launches at once -- one plan per stream;
- * uniform plans have no such limit. */
+ * ends): the same ragged plan must not run in two launches at once.  Launches on ONE stream are
+ * ordered and always fine; a launch on a different stream while the previous one has not finished
+ * returns OFDMTX_EBUSY (checked on the host with an event recorded behind every launch) -- use one
+ * plan per stream.  Uniform plans have no such limit.
+ * Lifetime: a plan must stay alive until the launches that use it have finished.
+ * ofdmtx_plan_destroy waits for the last launch of a ragged plan before it frees the plan's device
+ * tables; uniform plans own no device memory. */
 int ofdmtx_plan_ragged(ofdmtx_ctx *ctx, uint64_t n_pkts, const uint8_t *regimes,
                        const uint32_t *payload_len, const uint64_t *payload_off,
                        double symbol_time, int pilot_mode, uint32_t pilot_start, unsigned flags,
@@ -155,7 +180,9 @@ int ofdmtx_plan_ragged_device(ofdmtx_ctx *ctx, uint64_t n_pkts, const uint8_t *d
                               unsigned flags, float amp, void *stream, ofdmtx_plan **out);
 int ofdmtx_plan_destroy(ofdmtx_plan *plan);
 int ofdmtx_plan_get_sizes(const ofdmtx_plan *plan, ofdmtx_plan_sizes *out);
-/* Per-packet layout, host arrays of n_pkts entries each (any may be NULL):
+/* (on a plan from ofdmtx_plan_ragged_device the first call synchronises the device and copies the
+ * tables to the host: not reentrant for such a plan)
+ * Per-packet layout, host arrays of n_pkts entries each (any may be NULL):
  * plcp_off / msg_off byte offsets into tap / message buffers, sym_off index of the packet's
  * SIGNAL symbol in a `mapped` tap, sample_off index of the packet's first complex sample,
  * n_sym DATA symbols, pilot_base polarity index of the packet's SIGNAL symbol. */
@@ -178,6 +205,27 @@ int ofdmtx_encode_bits(ofdmtx_ctx *ctx, const ofdmtx_plan *plan, const uint8_t *
  * the mapper block's output.  d_iq: n_samples complex64 (re,im float32 pairs). */
 int ofdmtx_modulate(ofdmtx_ctx *ctx, const ofdmtx_plan *plan, const uint8_t *d_msg,
                     float *d_mapped, float *d_iq, void *stream);
+
+/* ofdmtx_modulate with the taps of the two blocks behind the mapper (the `--log` files of
+ * examples/ftw_ofdm.py:181-184): d_pilot = n_symbols x 53 complex64, the output of ofdm_pilot_cc
+ * ("ofdm_pilot.dat", ftw/ftw_ofdm_pilot_cc.cc:119-155); d_cmap = n_symbols x 64 complex64, the
+ * output of ofdm_cmap_cc = the input of the inverse FFT ("ofdm_cmap.dat",
+ * ftw/ftw_ofdm_cmap_cc.cc:102-107).  Any tap may be NULL.  The values are the ones the fused kernel
+ * feeds to its transform (read from the same registers). */
+int ofdmtx_modulate_taps(ofdmtx_ctx *ctx, const ofdmtx_plan *plan, const uint8_t *d_msg,
+                         float *d_mapped, float *d_pilot, float *d_cmap, float *d_iq, void *stream);
+/* The taps behind the transform (examples/ftw_ofdm.py:185-188), cut out of the IQ stream d_iq that
+ * ofdmtx_modulate / ofdmtx_tx wrote for `plan`.  The plan's amplitude must be 1 and OFDMTX_F_SWAPIQ
+ * unset (the reference taps sit in front of tx_amplitude and of the I/Q exchange): then every tap is
+ * the kernel's own output, at most rescaled by the exact factor 8 = sqrt(64):
+ *   d_ifft     n_symbols x 64   gr.fft_vcc output            ("ofdm_ifft.dat")     = 8 * row[16..79]
+ *   d_cp       n_symbols x 80   ofdm_cyclic_prefixer output  ("ofdm_cp_adder.dat") = 8 * row
+ *   d_scale    n_symbols x 80   multiply_const_cc(1/8)       ("ofdm_scale.dat")    = row
+ *   d_preamble per packet its preamble rows + symbol rows    ("ofdm_preamble.dat"); n_symbols +
+ *              n_pkts * (4, or 6 with a PNC role) rows of 80 (no rows added without OFDMTX_F_PREAMBLE)
+ * Any output may be NULL.  ("ofdm_zerogap.dat" is d_iq itself.) */
+int ofdmtx_symbol_taps(ofdmtx_ctx *ctx, const ofdmtx_plan *plan, const float *d_iq, float *d_ifft,
+                       float *d_cp, float *d_scale, float *d_preamble, void *stream);
 
 /* payload -> IQ for the whole batch (send_pkt + flowgraph) in one fused kernel.  d_work is
  * not used any more (the mapper messages stay in LDS) and may be NULL. */

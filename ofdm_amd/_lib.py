@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OFDMTX_LIB", os.path.join(_HERE, "libofdmtx.so"))
 
 OK = 0
-EINVAL, EREGIME, ELENGTH, EHIP, ENOMEM, ESHAPE, ETOOBIG = -1, -2, -3, -4, -5, -6, -7
+EINVAL, EREGIME, ELENGTH, EHIP, ENOMEM, ESHAPE, ETOOBIG, EBUSY = -1, -2, -3, -4, -5, -6, -7, -8
 F_PREAMBLE, F_ZEROGAP, F_SWAPIQ, F_PNC_A, F_PNC_B = 1, 2, 4, 8, 16
 PILOT_REF_STREAM, PILOT_PER_PACKET, PILOT_PNC_A, PILOT_PNC_B, PILOT_PNC_ALL = 0, 1, 2, 3, 4
 # status bits of the loop-back verifier (ofdmtx_rx_demod / ofdmtx_rx_decode)
@@ -47,8 +47,11 @@ PROTOTYPES = {
     "ofdmtx_create": (C.c_int, [C.c_int, C.POINTER(_VP)]),
     "ofdmtx_destroy": (C.c_int, [_VP]),
     "ofdmtx_set_constellation": (C.c_int, [_VP, C.c_int, _VP, C.c_int]),
+    "ofdmtx_set_preamble": (C.c_int, [_VP, _VP, C.c_int]),
+    "ofdmtx_set_gap": (C.c_int, [_VP, _VP, C.c_int]),
     "ofdmtx_get_table": (C.c_int, [C.c_int, _VP, C.c_int]),
     "ofdmtx_crc32": (C.c_uint32, [C.c_char_p, C.c_size_t]),
+    "ofdmtx_update_crc32": (C.c_uint32, [C.c_uint32, C.c_char_p, C.c_size_t]),
     "ofdmtx_packet_info": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_uint, C.POINTER(PktInfo)]),
     "ofdmtx_plan_uniform": (C.c_int, [_VP, C.c_uint64, C.c_int, C.c_uint32, C.c_uint64, C.c_double,
                                       C.c_int, C.c_uint32, C.c_uint, C.c_float, C.POINTER(_VP)]),
@@ -61,6 +64,8 @@ PROTOTYPES = {
     "ofdmtx_plan_get_layout": (C.c_int, [_VP] * 9),
     "ofdmtx_encode_bits": (C.c_int, [_VP] * 8),
     "ofdmtx_modulate": (C.c_int, [_VP] * 6),
+    "ofdmtx_modulate_taps": (C.c_int, [_VP] * 8),
+    "ofdmtx_symbol_taps": (C.c_int, [_VP] * 8),
     "ofdmtx_tx": (C.c_int, [_VP] * 6),
     "ofdmtx_scramble": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, _VP, _VP]),
     "ofdmtx_conv_encode": (C.c_int, [_VP, _VP, C.c_uint32, C.c_int, C.c_uint32, _VP, _VP]),
@@ -126,6 +131,11 @@ def packet_info(regime, payload_len, symbol_time=4.0, flags=F_PREAMBLE | F_ZEROG
 def crc32(data):
     data = bytes(data)
     return load().ofdmtx_crc32(data, len(data))
+
+
+def update_crc32(crc, data):
+    data = bytes(data)
+    return load().ofdmtx_update_crc32(int(crc) & 0xFFFFFFFF, data, len(data))
 
 
 def get_table(which):

@@ -22,6 +22,16 @@ def _stream(device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+def _check_buffer(name, t, dtype, device, numel):
+    """The kernels address caller buffers without bounds (the C ABI carries no sizes): every
+    buffer handed in is checked here -- dtype, device, contiguity and room for `numel` elements."""
+    if not torch.is_tensor(t) or t.dtype != dtype or t.device != device or not t.is_contiguous():
+        raise ValueError("%s must be a contiguous %s tensor on %s" % (name, str(dtype).replace("torch.", ""), device))
+    if t.numel() < numel:
+        raise ValueError("%s holds %d elements, the plan needs %d" % (name, t.numel(), numel))
+    return t
+
+
 class TxContext:
     """One per GPU: owns the device-side tables (scrambler words, constellations, preamble,
     twiddles)."""
@@ -51,6 +61,23 @@ class TxContext:
         pts = np.ascontiguousarray(np.asarray(points, dtype=np.complex64))
         _lib.check(self._lib.ofdmtx_set_constellation(self._h, int(n_bpsc), pts.ctypes.data, len(pts)))
 
+    def set_preamble(self, samples):
+        """`preamble` table of ftw.ofdm_preamble / ftw.pnc_ofdm_preamble: >= 320 complex samples, of
+        which the blocks emit the first four rows of 80."""
+        t = np.ascontiguousarray(np.asarray(samples, dtype=np.complex64).reshape(-1))
+        rc = self._lib.ofdmtx_set_preamble(self._h, t.ctypes.data, len(t))
+        if rc == _lib.EINVAL:
+            raise ValueError("preamble table must hold at least 4 x 80 samples, got %d" % len(t))
+        _lib.check(rc)
+
+    def set_gap(self, samples):
+        """`zerogap` row of ftw.zerogap / ftw.pnc_zerogap: one row of 80 complex samples."""
+        t = np.ascontiguousarray(np.asarray(samples, dtype=np.complex64).reshape(-1))
+        rc = self._lib.ofdmtx_set_gap(self._h, t.ctypes.data, len(t))
+        if rc == _lib.EINVAL:
+            raise ValueError("gap row must hold at least 80 samples, got %d" % len(t))
+        _lib.check(rc)
+
     def plan_uniform(self, n_pkts, regime, payload_len, payload_stride=0, symbol_time=4.0,
                      pilot_mode=_lib.PILOT_REF_STREAM, pilot_start=0,
                      flags=_lib.F_PREAMBLE | _lib.F_ZEROGAP, amp=0.3):
@@ -58,7 +85,7 @@ class TxContext:
         _lib.check(self._lib.ofdmtx_plan_uniform(self._h, int(n_pkts), int(regime), int(payload_len),
                                                  int(payload_stride), float(symbol_time), int(pilot_mode),
                                                  int(pilot_start), int(flags), float(amp), C.byref(h)))
-        return TxPlan(self, h)
+        return TxPlan(self, h, flags)
 
     def plan_ragged(self, regimes, payload_len, payload_off=None, symbol_time=4.0,
                     pilot_mode=_lib.PILOT_REF_STREAM, pilot_start=0,
@@ -82,7 +109,7 @@ class TxContext:
                                                 off.ctypes.data if off is not None else None,
                                                 float(symbol_time), int(pilot_mode), int(pilot_start),
                                                 int(flags), float(amp), C.byref(h)))
-        return TxPlan(self, h)
+        return TxPlan(self, h, flags)
 
 
     def _plan_ragged_device(self, regimes, payload_len, payload_off, symbol_time, pilot_mode, pilot_start, flags, amp):
@@ -101,16 +128,17 @@ class TxContext:
                                                        _ptr(payload_off), float(symbol_time), int(pilot_mode),
                                                        int(pilot_start), int(flags), float(amp), _stream(dev),
                                                        C.byref(h)))
-        return TxPlan(self, h)
+        return TxPlan(self, h, flags)
 
 
 class TxPlan:
     """Geometry of one batch (see include/ofdmtx.h, "plans")."""
 
-    def __init__(self, ctx, handle):
+    def __init__(self, ctx, handle, flags):
         self.ctx = ctx
         self._lib = ctx._lib
         self._h = handle
+        self.flags = int(flags)
         s = _lib.PlanSizes()
         _lib.check(self._lib.ofdmtx_plan_get_sizes(self._h, C.byref(s)))
         self.n_pkts = int(s.n_pkts)
@@ -158,19 +186,20 @@ class TxPlan:
         return torch.empty(self.n_samples, dtype=torch.complex64, device=self.ctx.device)
 
     def _check_payloads(self, payloads):
-        if payloads.dtype != torch.uint8 or payloads.device != self.ctx.device or not payloads.is_contiguous():
-            raise ValueError("payloads must be a contiguous uint8 tensor on %s" % self.ctx.device)
-        if payloads.numel() < self.payload_bytes:
-            raise ValueError("payload buffer holds %d bytes, plan reads %d" % (payloads.numel(), self.payload_bytes))
+        _check_buffer("payloads", payloads, torch.uint8, self.ctx.device, self.payload_bytes)
+
+    def _iq_out(self, out):
+        if out is None:
+            return self.alloc_iq()
+        return _check_buffer("iq buffer", out, torch.complex64, self.ctx.device, self.n_samples)
 
     # ---- kernels
     def encode_bits(self, payloads, taps=False, out=None):
         """Bit chain of send_pkt for the batch.  Returns the mapper-message buffer, or a dict
         with the plcp / scrambled / coded taps as well when taps=True."""
         self._check_payloads(payloads)
-        msg = out if out is not None else self.alloc_msg()
-        if msg.numel() < self.msg_bytes:
-            raise ValueError("message buffer too small")
+        msg = self.alloc_msg() if out is None else _check_buffer("message buffer", out, torch.uint8, self.ctx.device,
+                                                                 self.msg_bytes)
         plcp = scr = cod = None
         if taps:
             plcp, scr, cod = self._u8(self.plcp_bytes), self._u8(self.plcp_bytes), self._u8(self.msg_bytes)
@@ -180,24 +209,46 @@ class TxPlan:
             return {"plcp": plcp, "scrambled": scr, "coded": cod, "interleaved": msg}
         return msg
 
-    def modulate(self, msg, want_mapped=False, out=None):
-        """Mapper messages -> IQ stream (and the mapper block's symbols when want_mapped)."""
-        if msg.dtype != torch.uint8 or msg.device != self.ctx.device or msg.numel() < self.msg_bytes:
-            raise ValueError("message buffer must be uint8 on %s with >= %d bytes" % (self.ctx.device, self.msg_bytes))
-        iq = out if out is not None else self.alloc_iq()
-        if iq.numel() < self.n_samples or iq.dtype != torch.complex64:
-            raise ValueError("iq buffer must be complex64 with >= %d samples" % self.n_samples)
-        mapped = None
-        if want_mapped:
-            mapped = torch.empty((self.n_symbols, 48), dtype=torch.complex64, device=self.ctx.device)
-        _lib.check(self._lib.ofdmtx_modulate(self.ctx._h, self._h, _ptr(msg), _ptr(mapped), _ptr(iq),
-                                             _stream(self.ctx.device)))
+    def modulate(self, msg, want_mapped=False, out=None, taps=False):
+        """Mapper messages -> IQ stream (and the mapper block's symbols when want_mapped).
+        taps=True: (iq, dict) with the `mapped` (n_symbols x 48), `pilot` (x 53) and `cmap` (x 64) taps."""
+        _check_buffer("message buffer", msg, torch.uint8, self.ctx.device, self.msg_bytes)
+        iq = self._iq_out(out)
+        dev = self.ctx.device
+        mapped = pilot = cmap = None
+        if want_mapped or taps:
+            mapped = torch.empty((self.n_symbols, 48), dtype=torch.complex64, device=dev)
+        if taps:
+            pilot = torch.empty((self.n_symbols, 53), dtype=torch.complex64, device=dev)
+            cmap = torch.empty((self.n_symbols, 64), dtype=torch.complex64, device=dev)
+            _lib.check(self._lib.ofdmtx_modulate_taps(self.ctx._h, self._h, _ptr(msg), _ptr(mapped), _ptr(pilot),
+                                                      _ptr(cmap), _ptr(iq), _stream(dev)))
+            return iq, {"mapped": mapped, "pilot": pilot, "cmap": cmap}
+        _lib.check(self._lib.ofdmtx_modulate(self.ctx._h, self._h, _ptr(msg), _ptr(mapped), _ptr(iq), _stream(dev)))
         return (iq, mapped) if want_mapped else iq
+
+    def symbol_taps(self, iq):
+        """The taps behind the transform, cut out of this plan's IQ stream (plan amplitude 1, no I/Q
+        exchange): dict with `ifft` (n_symbols x 64), `cp` and `scale` (n_symbols x 80) and `preamble`
+        (per packet its preamble rows + symbol rows, rows of 80)."""
+        dev = self.ctx.device
+        _check_buffer("iq", iq, torch.complex64, dev, self.n_samples)
+        pre_rows = self.n_rows - self.n_symbols - (13 * self.n_pkts if self.flags & _lib.F_ZEROGAP else 0)
+        t = {"ifft": torch.empty((self.n_symbols, 64), dtype=torch.complex64, device=dev),
+             "cp": torch.empty((self.n_symbols, 80), dtype=torch.complex64, device=dev),
+             "scale": torch.empty((self.n_symbols, 80), dtype=torch.complex64, device=dev),
+             "preamble": torch.empty((self.n_symbols + pre_rows, 80), dtype=torch.complex64, device=dev)}
+        rc = self._lib.ofdmtx_symbol_taps(self.ctx._h, self._h, _ptr(iq), _ptr(t["ifft"]), _ptr(t["cp"]),
+                                          _ptr(t["scale"]), _ptr(t["preamble"]), _stream(dev))
+        if rc == _lib.EINVAL:
+            raise ValueError("symbol taps need a plan with amplitude 1 and without I/Q exchange")
+        _lib.check(rc)
+        return t
 
     def tx(self, payloads, out=None, work=None):
         """payload -> IQ for the whole batch."""
         self._check_payloads(payloads)
-        iq = out if out is not None else self.alloc_iq()
+        iq = self._iq_out(out)
         # (the fused kernel keeps the mapper messages in LDS: no work buffer is needed)
         _lib.check(self._lib.ofdmtx_tx(self.ctx._h, self._h, _ptr(payloads), _ptr(work), _ptr(iq),
                                        _stream(self.ctx.device)))
@@ -207,23 +258,24 @@ class TxPlan:
     def rx_demod(self, iq, out=None):
         """IQ stream of this plan's geometry -> (hard coded bits in the layout of the `coded` tap,
         per-packet status words)."""
-        if iq.dtype != torch.complex64 or iq.device != self.ctx.device or iq.numel() < self.n_samples:
-            raise ValueError("iq must be complex64 on %s with >= %d samples" % (self.ctx.device, self.n_samples))
-        coded = out if out is not None else self.alloc_msg()
-        status = torch.zeros(max(self.n_pkts, 1), dtype=torch.int32, device=self.ctx.device)
-        _lib.check(self._lib.ofdmtx_rx_demod(self.ctx._h, self._h, _ptr(iq), _ptr(coded), _ptr(status),
-                                             _stream(self.ctx.device)))
+        dev = self.ctx.device
+        _check_buffer("iq", iq, torch.complex64, dev, self.n_samples)
+        coded = self.alloc_msg() if out is None else _check_buffer("coded buffer", out, torch.uint8, dev, self.msg_bytes)
+        status = torch.zeros(max(self.n_pkts, 1), dtype=torch.int32, device=dev)
+        _lib.check(self._lib.ofdmtx_rx_demod(self.ctx._h, self._h, _ptr(iq), _ptr(coded), _ptr(status), _stream(dev)))
         return coded, status[:self.n_pkts]
 
     def rx_decode(self, coded, status=None):
         """Coded bits -> (payload bytes at the plan's payload offsets, status words; bits RX_*)."""
-        if coded.dtype != torch.uint8 or coded.device != self.ctx.device or coded.numel() < self.msg_bytes:
-            raise ValueError("coded buffer must be uint8 on %s with >= %d bytes" % (self.ctx.device, self.msg_bytes))
+        dev = self.ctx.device
+        _check_buffer("coded buffer", coded, torch.uint8, dev, self.msg_bytes)
         if status is None:
-            status = torch.zeros(max(self.n_pkts, 1), dtype=torch.int32, device=self.ctx.device)[:self.n_pkts]
-        payloads = torch.zeros(max(self.payload_bytes, 1), dtype=torch.uint8, device=self.ctx.device)
+            status = torch.zeros(max(self.n_pkts, 1), dtype=torch.int32, device=dev)[:self.n_pkts]
+        else:
+            _check_buffer("status", status, torch.int32, dev, self.n_pkts)
+        payloads = torch.zeros(max(self.payload_bytes, 1), dtype=torch.uint8, device=dev)
         _lib.check(self._lib.ofdmtx_rx_decode(self.ctx._h, self._h, _ptr(coded), _ptr(payloads), _ptr(status),
-                                              _stream(self.ctx.device)))
+                                              _stream(dev)))
         return payloads[:self.payload_bytes], status
 
     def loopback(self, iq):

@@ -40,6 +40,10 @@ struct ofdmtx_ctx {
     float2 *d_tw;
     uint32_t *d_crc;
     uint32_t *d_xpow8;
+    float2 *d_gap;              // the 80-sample row ftw.zerogap repeats behind every packet (zeros unless set)
+    bool gap_nonzero;
+    uint8_t *d_static;          // this device's copy of the library's static work area (ofdmtx.hip)
+    void *h_pinned;             // 256 page-locked bytes: totals read back by ofdmtx_tx_ragged_static
     int n_cu;
     DevTables tables() const;   // defined in ofdmtx.hip
 };

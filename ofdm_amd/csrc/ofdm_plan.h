@@ -148,4 +148,14 @@ struct ofdmtx_plan {
     uint32_t tx_u_words;   // ... for the scrambled words of the longest packet (payload input)
     uint32_t tx_m_words;   // ... for the message words of the longest packet (message input)
     uint32_t max_sym_rows; // largest n_sym + 1 of the plan
+    // Ragged plans share their device work counters between launches: an event recorded behind
+    // every launch tells whether the previous one (on `last_stream`) has finished.
+    mutable hipEvent_t busy_ev = nullptr;
+    mutable hipStream_t last_stream = nullptr;
+    mutable bool launched = false;
 };
+
+// ofdmtx.hip: OFDMTX_EBUSY if a ragged plan's previous launch is still running on another stream;
+// mark_launched records the event behind a launch just enqueued on `st`.
+int ofdmtx_plan_claim(const ofdmtx_plan *pl, hipStream_t st);
+int ofdmtx_plan_mark_launched(const ofdmtx_plan *pl, hipStream_t st);

@@ -7,8 +7,11 @@
 // Citations: pu = ftw_80211_ofdm_tx/src/examples/ftw_packet_utils.py of the reference.
 
 #include "ofdm_common.h"
+#include "ofdm_plan.h"
 
 namespace {
+
+using namespace ofdmtx_detail;
 
 struct StageRegime {
     int n_cbps, n_bpsc, punct;   // punct: 0 none, 1 = 3/4, 2 = 2/3
@@ -129,9 +132,65 @@ __global__ void k_repeat(const float4 *__restrict__ in, float4 *__restrict__ out
     for (uint64_t o = (uint64_t)blockIdx.y * period4 + j; o < total4; o += (uint64_t)gridDim.y * period4) out[o] = v;
 }
 
+// The taps behind the transform, cut out of a finished IQ stream (amplitude 1): per packet the
+// symbol rows (SIGNAL + DATA) sit behind the preamble rows.  scale = the rows themselves
+// (examples/ftw_ofdm.py:126 multiplies by 1/8), cp = the rows times 8 (the cyclic prefixer's output,
+// examples/ftw_ofdm.py:121-123), ifft = samples 16..79 of those (the transform's output,
+// examples/ftw_ofdm.py:118), pre = preamble rows + symbol rows (ftw/ftw_ofdm_preamble.cc:79-95).
+// Multiplying by 8 is exact in float32.  One workgroup per packet, 16 bytes per thread.
+__global__ void __launch_bounds__(256) k_symbol_taps(PlanParams P, const float4 *__restrict__ iq, float4 *__restrict__ ifft,
+                                                     float4 *__restrict__ cp, float4 *__restrict__ scale,
+                                                     float4 *__restrict__ pre)
+{
+    const uint32_t pre_rows = (P.flags & OFDMTX_F_PREAMBLE)
+                                  ? ((P.flags & (OFDMTX_F_PNC_A | OFDMTX_F_PNC_B)) ? PNC_PRE_ROWS : PRE_ROWS) : 0;
+    constexpr uint32_t Q = SYM_LEN / 2;                       // float4 per row
+    for (uint32_t p = blockIdx.x; p < P.n_pkts; p += gridDim.x) {
+        const size_t row0 = P.uniform ? (size_t)p * P.rows_per_pkt : (size_t)P.row_start[p];
+        const uint32_t n_sym = P.uniform ? P.n_sym : P.recs[p].n_sym;
+        const size_t sym0 = P.uniform ? (size_t)p * (P.n_sym + 1u) : (size_t)P.recs[p].sym_off;
+        const uint32_t rows = n_sym + 1u;
+        const float4 *src = iq + (row0 + pre_rows) * Q;
+        for (uint32_t i = threadIdx.x; i < rows * Q; i += blockDim.x) {
+            const uint32_t r = i / Q, c = i % Q;
+            const float4 v = src[i];
+            const float4 v8 = make_float4(v.x * 8.f, v.y * 8.f, v.z * 8.f, v.w * 8.f);
+            if (scale) scale[sym0 * Q + i] = v;
+            if (cp) cp[sym0 * Q + i] = v8;
+            if (ifft && c >= 8u) ifft[(sym0 + r) * 32u + (c - 8u)] = v8;
+        }
+        if (pre) {
+            float4 *dst = pre + (sym0 + (size_t)p * pre_rows) * Q;
+            const float4 *s2 = iq + row0 * Q;
+            for (uint32_t i = threadIdx.x; i < (pre_rows + rows) * Q; i += blockDim.x) dst[i] = s2[i];
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int ofdmtx_symbol_taps(ofdmtx_ctx *ctx, const ofdmtx_plan *pl, const float *d_iq, float *d_ifft, float *d_cp,
+                       float *d_scale, float *d_preamble, void *stream)
+{
+    if (!ctx || !pl || pl->ctx != ctx) return OFDMTX_EINVAL;
+    // the taps sit in front of tx_amplitude and of the I/Q exchange: only then are they the kernel's own samples
+    if (pl->pp.amp != 1.0f || (pl->pp.flags & OFDMTX_F_SWAPIQ)) return OFDMTX_EINVAL;
+    if (pl->pp.n_pkts == 0) return OFDMTX_OK;
+    if (!d_iq) return OFDMTX_EINVAL;
+    if (((uintptr_t)d_iq | (uintptr_t)d_ifft | (uintptr_t)d_cp | (uintptr_t)d_scale | (uintptr_t)d_preamble) & 15u)
+        return OFDMTX_EINVAL;                                                 // 16-byte accesses
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint32_t n = pl->pp.n_pkts;
+    const uint32_t cap = (uint32_t)ctx->n_cu * 8u;
+    hipLaunchKernelGGL(k_symbol_taps, dim3(n < cap ? n : cap), dim3(256), 0, (hipStream_t)stream, pl->pp,
+                       reinterpret_cast<const float4 *>(d_iq), reinterpret_cast<float4 *>(d_ifft),
+                       reinterpret_cast<float4 *>(d_cp), reinterpret_cast<float4 *>(d_scale),
+                       reinterpret_cast<float4 *>(d_preamble));
+    HIPCHK(hipGetLastError());
+    return OFDMTX_OK;
+}
 
 int ofdmtx_scramble(ofdmtx_ctx *ctx, const uint8_t *d_in, uint32_t n_bytes, uint32_t length_data, uint8_t *d_out,
                     void *stream)

@@ -783,7 +783,8 @@ constexpr int TX_B_WORDS = 8 * RS * 2;
 template <bool UNIFORM, int REGIME, bool FROM_MSG, bool PNC = false>
 __global__ void __launch_bounds__(64 * TX_MAX_WAVES)
 k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ in, float2 *__restrict__ mapped,
-     float2 *__restrict__ iq, uint32_t a_words, uint32_t u_off, uint32_t wave_words)
+     float2 *__restrict__ pilot_tap, float2 *__restrict__ cmap_tap, float2 *__restrict__ iq, uint32_t a_words,
+     uint32_t u_off, uint32_t wave_words)
 {
     extern __shared__ __align__(16) uint32_t s_dyn[];
     __shared__ uint32_t s_crc[FROM_MSG ? 1 : 1024];
@@ -1022,6 +1023,18 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ in, float2 *__restri
                             if (c >= 0) mrow[c] = make_float2(x[m].x, x[m].y);
                         }
                     }
+                    // taps: the pilot block's 53 carriers (-26..+26, ftw/ftw_ofdm_pilot_cc.cc:119-155) and
+                    // the carrier map's 64 bins (ftw/ftw_ofdm_cmap_cc.cc:102-107), i.e. the transform's input
+                    if ((pilot_tap || cmap_tap) && active) {
+                        const size_t sym = (size_t)k.sym_off + row_base + r0 + (uint32_t)g;
+#pragma unroll
+                        for (int m = 0; m < 8; m++) {
+                            const int bin = l + 8 * m;
+                            const int f = bin < 32 ? bin : bin - 64;
+                            if (cmap_tap) cmap_tap[sym * 64u + (uint32_t)bin] = make_float2(x[m].x, x[m].y);
+                            if (pilot_tap && f >= -26 && f <= 26) pilot_tap[sym * 53u + (uint32_t)(f + 26)] = make_float2(x[m].x, x[m].y);
+                        }
+                    }
                 }
                 ifft64_emit(active, x, l, g, lane_r, buf, reinterpret_cast<const v2f *>(s_tw), swap_iq, win,
                             (pre_rows + row_base + r0) * (SYM_LEN / 2),
@@ -1191,6 +1204,26 @@ __global__ void k_plan_fill(uint32_t n, unsigned long long *__restrict__ col, si
     recs[i] = r;
 }
 
+// ftw/ftw_zerogap.cc:88-92 with a gap row that is not all zeros: the 13 rows behind every packet
+// are copies of the context's row, times the plan's amplitude (I and Q exchanged if asked).  Runs
+// behind k_tx, which has written zeros there.  One workgroup per packet.
+__global__ void __launch_bounds__(256) k_gap_rows(PlanParams P, const float2 *__restrict__ gap, float2 *__restrict__ iq)
+{
+    __shared__ __align__(16) float2 s_gap[SYM_LEN];
+    const bool swap_iq = (P.flags & OFDMTX_F_SWAPIQ) != 0;
+    for (int i = threadIdx.x; i < SYM_LEN; i += blockDim.x) {
+        const float2 v = gap[i];
+        s_gap[i] = swap_iq ? make_float2(v.y * P.amp, v.x * P.amp) : make_float2(v.x * P.amp, v.y * P.amp);
+    }
+    __syncthreads();
+    const float4 *g4 = reinterpret_cast<const float4 *>(s_gap);
+    for (uint32_t p = blockIdx.x; p < P.n_pkts; p += gridDim.x) {
+        const size_t row_end = P.uniform ? (size_t)(p + 1u) * P.rows_per_pkt : (size_t)P.row_start[p + 1u];
+        float4 *dst = reinterpret_cast<float4 *>(iq + (row_end - GAP_ROWS) * SYM_LEN);
+        for (uint32_t i = threadIdx.x; i < GAP_ROWS * SYM_LEN / 2; i += blockDim.x) dst[i] = g4[i % (SYM_LEN / 2)];
+    }
+}
+
 }  // namespace
 
 thread_local int ofdmtx_g_last_hip = 0;
@@ -1225,6 +1258,7 @@ const char *ofdmtx_strerror(int code)
     case OFDMTX_ENOMEM: return "out of memory";
     case OFDMTX_ESHAPE: return "block shape not supported (802.11a needs 48 data carriers, 64-point FFT)";
     case OFDMTX_ETOOBIG: return "batch too large for one launch";
+    case OFDMTX_EBUSY: return "ragged plan still running on another stream";
     default: return "unknown error";
     }
 }
@@ -1242,6 +1276,12 @@ uint32_t ofdmtx_crc32(const uint8_t *buf, size_t len)
     uint32_t rev = 0;
     for (int j = 0; j < 32; j++) rev |= ((crc >> j) & 1u) << (31 - j);
     return rev ^ 0xFFFFFFFFu;
+}
+
+uint32_t ofdmtx_update_crc32(uint32_t crc, const uint8_t *buf, size_t len)
+{
+    (void)crc;   // ftw/ftw_crc32.cc:53 restarts from all ones whatever it is given
+    return ofdmtx_crc32(buf, len) ^ 0xFFFFFFFFu;
 }
 
 int ofdmtx_packet_info(int regime, int payload_len, double symbol_time, unsigned flags,
@@ -1275,13 +1315,21 @@ int ofdmtx_create(int device, ofdmtx_ctx **out)
     ofdmtx_ctx *c = new (std::nothrow) ofdmtx_ctx();
     if (!c) return OFDMTX_ENOMEM;
     c->device = device;
-    hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, device));
-    c->n_cu = prop.multiProcessorCount;
-    HIPCHK(hipMalloc(&c->d_scr, 127 * sizeof(uint32_t)));
-    HIPCHK(hipMalloc(&c->d_lut, LUT_SIZE * sizeof(float2)));
-    HIPCHK(hipMalloc(&c->d_pre, 320 * sizeof(float2)));
-    HIPCHK(hipMalloc(&c->d_tw, 64 * sizeof(float2)));
+    // CRC helper tables: slicing-by-4 and the powers x^(8n) mod P used to merge lane chunks
+    std::vector<uint32_t> tab(1024), xp(MAXLEN + 1);
+    for (uint32_t b = 0; b < 256; b++) {
+        uint32_t crc = b;
+        for (int j = 0; j < 8; j++) crc = (crc >> 1) ^ (CRC_POLY & (0u - (crc & 1u)));   // ftw/ftw_crc32.cc:41-48
+        tab[b] = crc;
+    }
+    for (int t = 1; t < 4; t++)
+        for (uint32_t b = 0; b < 256; b++)
+            tab[256 * t + b] = (tab[256 * (t - 1) + b] >> 8) ^ tab[tab[256 * (t - 1) + b] & 0xFFu];
+    uint32_t v = 0x80000000u;
+    for (int n = 0; n <= MAXLEN; n++) {
+        xp[n] = v;
+        for (int j = 0; j < 8; j++) v = (v >> 1) ^ (CRC_POLY & (0u - (v & 1u)));
+    }
     float lut[2 * LUT_SIZE];
     memset(lut, 0, sizeof(lut));
     lut[2 * LUT_PM1] = -1.f; lut[2 * LUT_PM1 + 2] = 1.f;        // ftw/ftw_ofdm_mapper.cc:179, pilots
@@ -1289,30 +1337,30 @@ int ofdmtx_create(int device, ofdmtx_ctx **out)
     memcpy(lut + 2 * 8, OFDMTX_CONST_DEFAULT + 2 * 2, 2 * 4 * sizeof(float));     // QPSK
     memcpy(lut + 2 * 16, OFDMTX_CONST_DEFAULT + 2 * 6, 2 * 16 * sizeof(float));   // 16-QAM
     memcpy(lut + 2 * 64, OFDMTX_CONST_DEFAULT + 2 * 22, 2 * 64 * sizeof(float));  // 64-QAM
-    HIPCHK(hipMemcpy(c->d_scr, OFDMTX_SCR_WORD, sizeof(OFDMTX_SCR_WORD), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(c->d_lut, lut, sizeof(lut), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(c->d_pre, OFDMTX_PREAMBLE, sizeof(OFDMTX_PREAMBLE), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(c->d_tw, OFDMTX_TW64, sizeof(OFDMTX_TW64), hipMemcpyHostToDevice));
-    {
-        // CRC helper tables: slicing-by-4 and the powers x^(8n) mod P used to merge lane chunks
-        std::vector<uint32_t> tab(1024), xp(MAXLEN + 1);
-        for (uint32_t b = 0; b < 256; b++) {
-            uint32_t crc = b;
-            for (int j = 0; j < 8; j++) crc = (crc >> 1) ^ (CRC_POLY & (0u - (crc & 1u)));   // ftw/ftw_crc32.cc:41-48
-            tab[b] = crc;
-        }
-        for (int t = 1; t < 4; t++)
-            for (uint32_t b = 0; b < 256; b++)
-                tab[256 * t + b] = (tab[256 * (t - 1) + b] >> 8) ^ tab[tab[256 * (t - 1) + b] & 0xFFu];
-        uint32_t v = 0x80000000u;
-        for (int n = 0; n <= MAXLEN; n++) {
-            xp[n] = v;
-            for (int j = 0; j < 8; j++) v = (v >> 1) ^ (CRC_POLY & (0u - (v & 1u)));
-        }
-        HIPCHK(hipMalloc(&c->d_crc, tab.size() * sizeof(uint32_t)));
-        HIPCHK(hipMalloc(&c->d_xpow8, xp.size() * sizeof(uint32_t)));
-        HIPCHK(hipMemcpy(c->d_crc, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(c->d_xpow8, xp.data(), xp.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+
+    // every step runs only while the ones before it succeeded; one exit frees whatever exists
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e == hipSuccess) c->n_cu = prop.multiProcessorCount;
+    if (e == hipSuccess) e = hipMalloc(&c->d_scr, 127 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&c->d_lut, LUT_SIZE * sizeof(float2));
+    if (e == hipSuccess) e = hipMalloc(&c->d_pre, 320 * sizeof(float2));
+    if (e == hipSuccess) e = hipMalloc(&c->d_tw, 64 * sizeof(float2));
+    if (e == hipSuccess) e = hipMalloc(&c->d_gap, SYM_LEN * sizeof(float2));
+    if (e == hipSuccess) e = hipMalloc(&c->d_crc, tab.size() * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&c->d_xpow8, xp.size() * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipHostMalloc(&c->h_pinned, 256, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMemcpy(c->d_scr, OFDMTX_SCR_WORD, sizeof(OFDMTX_SCR_WORD), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(c->d_lut, lut, sizeof(lut), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(c->d_pre, OFDMTX_PREAMBLE, sizeof(OFDMTX_PREAMBLE), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(c->d_tw, OFDMTX_TW64, sizeof(OFDMTX_TW64), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(c->d_gap, 0, SYM_LEN * sizeof(float2));       // pu:510: 80 zeros
+    if (e == hipSuccess) e = hipMemcpy(c->d_crc, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(c->d_xpow8, xp.data(), xp.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        ofdmtx_g_last_hip = (int)e;
+        ofdmtx_destroy(c);
+        return OFDMTX_EHIP;
     }
     *out = c;
     return OFDMTX_OK;
@@ -1322,13 +1370,38 @@ int ofdmtx_destroy(ofdmtx_ctx *c)
 {
     if (!c) return OFDMTX_EINVAL;
     (void)hipSetDevice(c->device);
-    (void)hipFree(c->d_scr);
-    (void)hipFree(c->d_lut);
-    (void)hipFree(c->d_pre);
-    (void)hipFree(c->d_tw);
-    (void)hipFree(c->d_crc);
-    (void)hipFree(c->d_xpow8);
+    if (c->d_scr) (void)hipFree(c->d_scr);
+    if (c->d_lut) (void)hipFree(c->d_lut);
+    if (c->d_pre) (void)hipFree(c->d_pre);
+    if (c->d_tw) (void)hipFree(c->d_tw);
+    if (c->d_gap) (void)hipFree(c->d_gap);
+    if (c->d_crc) (void)hipFree(c->d_crc);
+    if (c->d_xpow8) (void)hipFree(c->d_xpow8);
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     delete c;
+    return OFDMTX_OK;
+}
+
+int ofdmtx_set_preamble(ofdmtx_ctx *c, const float *re_im, int n_samples)
+{
+    if (!c || !re_im) return OFDMTX_EINVAL;
+    if (n_samples < PRE_ROWS * SYM_LEN) return OFDMTX_EINVAL;   // the blocks copy four rows of 80 (ftw/ftw_ofdm_preamble.cc:79-83)
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());                             // kernels in flight still read the old table
+    HIPCHK(hipMemcpy(c->d_pre, re_im, (size_t)PRE_ROWS * SYM_LEN * sizeof(float2), hipMemcpyHostToDevice));
+    return OFDMTX_OK;
+}
+
+int ofdmtx_set_gap(ofdmtx_ctx *c, const float *re_im, int n_samples)
+{
+    if (!c || !re_im) return OFDMTX_EINVAL;
+    if (n_samples < SYM_LEN) return OFDMTX_EINVAL;              // one row of 80 (ftw/ftw_zerogap.cc:88-92)
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(c->d_gap, re_im, (size_t)SYM_LEN * sizeof(float2), hipMemcpyHostToDevice));
+    bool nz = false;
+    for (int i = 0; i < 2 * SYM_LEN; i++) nz = nz || re_im[i] != 0.f;
+    c->gap_nonzero = nz;
     return OFDMTX_OK;
 }
 
@@ -1345,6 +1418,7 @@ int ofdmtx_set_constellation(ofdmtx_ctx *c, int n_bpsc, const float *re_im, int 
     }
     if (n != (1 << n_bpsc)) return OFDMTX_EINVAL;
     HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());                             // kernels in flight still read the old table
     HIPCHK(hipMemcpy(c->d_lut + off, re_im, (size_t)n * sizeof(float2), hipMemcpyHostToDevice));
     return OFDMTX_OK;
 }
@@ -1550,6 +1624,7 @@ int ofdmtx_plan_ragged(ofdmtx_ctx *ctx, uint64_t n_pkts, const uint8_t *regimes,
     sz.n_samples = rows * SYM_LEN;
 
     hipError_t e = hipSetDevice(ctx->device);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&pl->busy_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc(&pl->d_recs, (n_pkts ? n_pkts : 1) * sizeof(PktRec));
     // the fused kernel's work counter sits behind the row table, on a 256-byte line of its own
     const size_t counter_at = (((size_t)n_pkts + 1) * sizeof(uint32_t) + 255u) & ~(size_t)255u;
@@ -1598,7 +1673,8 @@ int ofdmtx_plan_ragged_device(ofdmtx_ctx *ctx, uint64_t n_pkts, const uint8_t *d
     PlanDevOut *d_out = nullptr;
     PlanDevOut h = {};
     unsigned long long totals[PLAN_COLS] = {};
-    hipError_t e = hipMalloc(&pl->d_recs, (n_pkts ? n_pkts : 1) * sizeof(PktRec));
+    hipError_t e = hipEventCreateWithFlags(&pl->busy_ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc(&pl->d_recs, (n_pkts ? n_pkts : 1) * sizeof(PktRec));
     if (e == hipSuccess) e = hipMalloc(&pl->d_row_start, counter_at + 256);
     if (e == hipSuccess) e = hipMalloc(&pl->d_plcp_len, (n_pkts ? n_pkts : 1) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&pl->d_msg_len, (n_pkts ? n_pkts : 1) * sizeof(uint32_t));
@@ -1672,6 +1748,10 @@ int ofdmtx_plan_destroy(ofdmtx_plan *pl)
 {
     if (!pl) return OFDMTX_EINVAL;
     (void)hipSetDevice(pl->device);
+    if (pl->busy_ev) {
+        if (pl->launched) (void)hipEventSynchronize(pl->busy_ev);   // the last launch still reads the tables
+        (void)hipEventDestroy(pl->busy_ev);
+    }
     if (pl->d_recs) (void)hipFree(pl->d_recs);
     if (pl->d_row_start) (void)hipFree(pl->d_row_start);
     if (pl->d_plcp_len) (void)hipFree(pl->d_plcp_len);
@@ -1739,6 +1819,31 @@ int ofdmtx_plan_get_layout(const ofdmtx_plan *pl, uint64_t *plcp_off, uint64_t *
     return OFDMTX_OK;
 }
 
+}  // extern "C" (interrupted for two helpers shared with the other translation units)
+
+int ofdmtx_plan_claim(const ofdmtx_plan *pl, hipStream_t st)
+{
+    if (pl->pp.uniform || !pl->launched || st == pl->last_stream) return OFDMTX_OK;
+    const hipError_t e = hipEventQuery(pl->busy_ev);
+    if (e == hipErrorNotReady) return OFDMTX_EBUSY;
+    if (e != hipSuccess) {
+        ofdmtx_g_last_hip = (int)e;
+        return OFDMTX_EHIP;
+    }
+    return OFDMTX_OK;
+}
+
+int ofdmtx_plan_mark_launched(const ofdmtx_plan *pl, hipStream_t st)
+{
+    if (pl->pp.uniform || !pl->busy_ev) return OFDMTX_OK;   // (no event: the transient plan of the allocation-free call)
+    HIPCHK(hipEventRecord(pl->busy_ev, st));
+    pl->last_stream = st;
+    pl->launched = true;
+    return OFDMTX_OK;
+}
+
+extern "C" {
+
 static int grid_for(const ofdmtx_ctx *c, uint64_t work_items, int items_per_block, int blocks_per_cu)
 {
     uint64_t need = (work_items + items_per_block - 1) / items_per_block;
@@ -1758,6 +1863,7 @@ int ofdmtx_encode_bits(ofdmtx_ctx *ctx, const ofdmtx_plan *pl, const uint8_t *d_
     HIPCHK(hipSetDevice(ctx->device));
     const int grid = grid_for(ctx, pl->pp.n_pkts, ENC_WAVES, 8);
     hipStream_t st = (hipStream_t)stream;
+    if (int rc = ofdmtx_plan_claim(pl, st)) return rc;
     const PlanParams &pp = pl->pp;
     const DevTables tab = ctx->tables();
 #define LAUNCH_ENC(U_, R_)                                                                           \
@@ -1779,16 +1885,17 @@ int ofdmtx_encode_bits(ofdmtx_ctx *ctx, const ofdmtx_plan *pl, const uint8_t *d_
     }
 #undef LAUNCH_ENC
     HIPCHK(hipGetLastError());
-    return OFDMTX_OK;
+    return ofdmtx_plan_mark_launched(pl, st);
 }
 
 }  // extern "C"
 
 // Launch of the wave-per-packet kernel for either input (payloads or mapper messages).
 template <bool FROM_MSG>
-static int launch_tx(ofdmtx_ctx *ctx, const ofdmtx_plan *pl, const uint8_t *d_in, float2 *mapped, float2 *iq,
-                     hipStream_t st)
+static int launch_tx(ofdmtx_ctx *ctx, const ofdmtx_plan *pl, const uint8_t *d_in, float2 *mapped, float2 *pilot_tap,
+                     float2 *cmap_tap, float2 *iq, hipStream_t st)
 {
+    if (int rc = ofdmtx_plan_claim(pl, st)) return rc;
     // one chunk: the scrambled / message words share the staging area; several chunks: they need
     // a region of their own
     const bool one_chunk = pl->max_sym_rows <= 65u;
@@ -1820,7 +1927,7 @@ static int launch_tx(ofdmtx_ctx *ctx, const ofdmtx_plan *pl, const uint8_t *d_in
         const int grid = grid_for(ctx, pl->pp.n_pkts, waves, per_cu);                                \
         HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));       \
         hipLaunchKernelGGL((k_tx<U_, R_, FROM_MSG, ##__VA_ARGS__>), dim3(grid), dim3(64 * waves), lds, st, pp, \
-                           tab, d_in, mapped, iq, a_words, u_off, wave_words);                       \
+                           tab, d_in, mapped, pilot_tap, cmap_tap, iq, a_words, u_off, wave_words);  \
     } while (0)
     const bool pnc = (pp.flags & (OFDMTX_F_PNC_A | OFDMTX_F_PNC_B)) || pp.pilot_mode >= OFDMTX_PILOT_PNC_A;
     if (pnc) {
@@ -1849,7 +1956,12 @@ static int launch_tx(ofdmtx_ctx *ctx, const ofdmtx_plan *pl, const uint8_t *d_in
     }
 #undef LAUNCH_TX
     HIPCHK(hipGetLastError());
-    return OFDMTX_OK;
+    if (ctx->gap_nonzero && (pp.flags & OFDMTX_F_ZEROGAP)) {
+        // a gap row other than zeros (ofdmtx_set_gap): written over the zeros k_tx has just stored
+        hipLaunchKernelGGL(k_gap_rows, dim3(grid_for(ctx, pp.n_pkts, 1, 8)), dim3(256), 0, st, pp, ctx->d_gap, iq);
+        HIPCHK(hipGetLastError());
+    }
+    return ofdmtx_plan_mark_launched(pl, st);
 }
 
 extern "C" {
@@ -1861,8 +1973,19 @@ int ofdmtx_modulate(ofdmtx_ctx *ctx, const ofdmtx_plan *pl, const uint8_t *d_msg
     if (pl->pp.n_pkts == 0) return OFDMTX_OK;
     if (!d_msg || !d_iq) return OFDMTX_EINVAL;
     HIPCHK(hipSetDevice(ctx->device));
-    return launch_tx<true>(ctx, pl, d_msg, reinterpret_cast<float2 *>(d_mapped), reinterpret_cast<float2 *>(d_iq),
-                           (hipStream_t)stream);
+    return launch_tx<true>(ctx, pl, d_msg, reinterpret_cast<float2 *>(d_mapped), nullptr, nullptr,
+                           reinterpret_cast<float2 *>(d_iq), (hipStream_t)stream);
+}
+
+int ofdmtx_modulate_taps(ofdmtx_ctx *ctx, const ofdmtx_plan *pl, const uint8_t *d_msg, float *d_mapped,
+                         float *d_pilot, float *d_cmap, float *d_iq, void *stream)
+{
+    if (!ctx || !pl || pl->ctx != ctx) return OFDMTX_EINVAL;
+    if (pl->pp.n_pkts == 0) return OFDMTX_OK;
+    if (!d_msg || !d_iq) return OFDMTX_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    return launch_tx<true>(ctx, pl, d_msg, reinterpret_cast<float2 *>(d_mapped), reinterpret_cast<float2 *>(d_pilot),
+                           reinterpret_cast<float2 *>(d_cmap), reinterpret_cast<float2 *>(d_iq), (hipStream_t)stream);
 }
 
 int ofdmtx_tx(ofdmtx_ctx *ctx, const ofdmtx_plan *pl, const uint8_t *d_payloads, uint8_t *d_work,
@@ -1874,7 +1997,8 @@ int ofdmtx_tx(ofdmtx_ctx *ctx, const ofdmtx_plan *pl, const uint8_t *d_payloads,
     if (!d_iq) return OFDMTX_EINVAL;
     if (!d_payloads && pl->sizes.payload_bytes) return OFDMTX_EINVAL;
     HIPCHK(hipSetDevice(ctx->device));
-    return launch_tx<false>(ctx, pl, d_payloads, nullptr, reinterpret_cast<float2 *>(d_iq), (hipStream_t)stream);
+    return launch_tx<false>(ctx, pl, d_payloads, nullptr, nullptr, nullptr, reinterpret_cast<float2 *>(d_iq),
+                            (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -1,7 +1,9 @@
 """Factories with the names and signatures of the reference's SWIG module `gnuradio.ftw`
 (ftw_80211_ofdm_tx/src/ftw/ftw.i:42-218).  The objects carry the block parameters and check
 them the way the C++ constructors / work functions do; the arithmetic of all of them runs fused
-in the HIP kernels (ofdmtx_modulate / ofdmtx_tx), driven by ofdm_amd.ftw_ofdm.ofdm_mod.
+in the HIP kernels (ofdmtx_modulate / ofdmtx_tx), driven by ofdm_amd.ftw_ofdm.ofdm_mod, which
+hands every held parameter to the library: the mapper's constellation (ofdmtx_set_constellation),
+the preamble table (ofdmtx_set_preamble) and the gap row (ofdmtx_set_gap).
 """
 from . import _lib
 from . import gr
@@ -15,8 +17,11 @@ def ftw_crc32(s):
 
 
 def ftw_update_crc32(crc, s):
-    raise NotImplementedError("ftw_update_crc32 ignores its crc argument in the reference "
-                              "(ftw_crc32.cc:53); use ftw_crc32")
+    """ftw.i:215-218, ftw_crc32.cc:33-64: the bit-reversed CRC register after `s`, without the final
+    inversion; `crc` is accepted and ignored as there (ftw_crc32.cc:53 restarts from all ones)."""
+    if isinstance(s, str):
+        s = s.encode("latin-1")
+    return _lib.update_crc32(crc, s)
 
 
 class ofdm_mapper(object):
@@ -78,13 +83,23 @@ class ofdm_cmap_cc(object):
             raise RuntimeError("ftw_ofdm_cmap_cc: IEEE 802.11p requires 64 FFT size\n")
 
 
+def _rows_for_80(symbol_length, what):
+    # the fused kernel writes rows of 80 samples (64-point transform + 16 samples of cyclic prefix)
+    if int(symbol_length) != 80:
+        raise RuntimeError("%s: symbol_length must be 80 (%s)" % (what, _lib.load().ofdmtx_strerror(_lib.ESHAPE).decode()))
+
+
 class ofdm_preamble(object):
-    """ftw.i:78-90, ftw_ofdm_preamble.cc:39-99: four rows of symbol_length samples in front of
-    every packet."""
+    """ftw.i:78-90, ftw_ofdm_preamble.cc:39-99: the first four rows of symbol_length samples of
+    preamble[0] in front of every packet (:79-83)."""
 
     def __init__(self, symbol_length, N_symbols, preamble):
+        _rows_for_80(symbol_length, "ftw_ofdm_preamble")
         self.symbol_length, self.N_symbols = symbol_length, N_symbols
         self.preamble = [list(p) for p in preamble]
+        if not self.preamble or len(self.preamble[0]) < 4 * symbol_length:
+            # the reference would copy from beyond the table
+            raise ValueError("ftw_ofdm_preamble: preamble[0] must hold 4 x %d samples" % symbol_length)
 
 
 class pnc_ofdm_preamble(object):
@@ -95,8 +110,11 @@ class pnc_ofdm_preamble(object):
     def __init__(self, symbol_length, N_symbols, preamble, user):
         if int(user) not in (1, 2):                                 # :105 only prints an error
             raise RuntimeError("ERROR: user not set properly! [FTW_PNC_PREAMBLE]")
+        _rows_for_80(symbol_length, "ftw_pnc_ofdm_preamble")
         self.symbol_length, self.N_symbols, self.user = symbol_length, N_symbols, int(user)
         self.preamble = [list(p) for p in preamble]
+        if not self.preamble or len(self.preamble[0]) < 4 * symbol_length:
+            raise ValueError("ftw_pnc_ofdm_preamble: preamble[0] must hold 4 x %d samples" % symbol_length)
 
     @property
     def flags(self):
@@ -104,11 +122,15 @@ class pnc_ofdm_preamble(object):
 
 
 class zerogap(object):
-    """ftw.i:110-122, ftw_zerogap.cc:39-102: 13 rows of zeros behind every packet."""
+    """ftw.i:110-122, ftw_zerogap.cc:39-102: gap[0] (one row of symbol_length samples; the
+    reference passes zeros) 13 times behind every packet (:88-92)."""
 
     def __init__(self, symbol_length, N_symbols, gap):
+        _rows_for_80(symbol_length, "ftw_zerogap")
         self.symbol_length, self.N_symbols = symbol_length, N_symbols
         self.gap = [list(g) for g in gap]
+        if not self.gap or len(self.gap[0]) < symbol_length:
+            raise ValueError("ftw_zerogap: gap[0] must hold %d samples" % symbol_length)
 
 
 class pnc_zerogap(zerogap):

@@ -8,6 +8,7 @@ here only queues the payload; queued packets are modulated as ONE batch by the f
 The pilot polarity counter runs on over all packets of the process, as the reference's global
 counter does (ftw/ftw_ofdm_pilot_cc.cc:82,159).
 """
+import collections
 import math
 
 import numpy as np
@@ -17,6 +18,7 @@ from . import _lib
 from . import ftw
 from . import gr
 from . import ftw_packet_utils as ofdm_packet_utils
+from .batch import TxContext
 
 # symbols modulated so far in this process (ftw/ftw_ofdm_pilot_cc.cc:82: a file-scope counter)
 _pilot_offset = [0]
@@ -73,20 +75,28 @@ class ofdm_mod(gr.hier_block2):
 
         self._swap = bool(getattr(options, "swapIQ", False))
         self._log = bool(getattr(options, "log", False))
-        self._ctx = ofdm_packet_utils._context(device)
+        # This block chain owns its library context: the mapper's constellation, the preamble table
+        # and the gap row are per-instance block arguments in the reference (ftw/ftw.i:78-122,157-163).
+        if device is None:
+            device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+        self._ctx = TxContext(device)
         self._ctx.set_constellation(self._pkt_input.nbits, rotated_const)
+        self._ctx.set_preamble(self.preamble.preamble[0])            # ftw/ftw_ofdm_preamble.cc:79-83 reads row 0
+        self._ctx.set_gap(self.zerogap.gap[0])                       # ftw/ftw_zerogap.cc:88-92 reads row 0
         self._batch_packets = int(batch_packets)
         self._pending = []
-        self._gain = None
-        self._sinks = []
+        self._outs = []              # (multiply_const_cc or None, sink) per connection
         self._eof = False
         self._log_files = {}
+        self._plans = collections.OrderedDict()    # uniform plans of recent batches
+        self._live = []              # plans and buffers of the last flush: kept until the next one has been enqueued
+        self._pinned = None          # page-locked staging buffer for the payload bytes
+        self._pinned_free = None     # event: the copy out of it has finished
+        self._dev_payloads = None
 
     # ---- wiring (ofdm_amd.gr.top_block.connect)
     def _attach(self, gain, sinks):
-        if gain is not None:
-            self._gain = gain
-        self._sinks.extend(sinks)
+        self._outs.extend((gain, s) for s in sinks)
 
     def _start(self):
         pass
@@ -116,45 +126,98 @@ class ofdm_mod(gr.hier_block2):
             self._log_files[name] = open(name, "wb")
         t.cpu().numpy().tofile(self._log_files[name])
 
+    def _stage_payloads(self, pk, total):
+        """Payload bytes -> device through a page-locked buffer that is kept between flushes (a
+        pageable source makes the runtime stage every copy itself, at a fraction of the link rate)."""
+        dev = self._ctx.device
+        need = max(total, 1)
+        if self._pinned is None or self._pinned.numel() < need:
+            cap = max(need, 1 << 20, 2 * (self._pinned.numel() if self._pinned is not None else 0))
+            if self._pinned_free is not None:
+                self._pinned_free.synchronize()
+            self._pinned = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
+            self._dev_payloads = torch.empty(cap, dtype=torch.uint8, device=dev)
+        elif self._pinned_free is not None:
+            self._pinned_free.synchronize()                     # the previous copy still reads the buffer
+        host = self._pinned.numpy()
+        off = 0
+        for b in pk:
+            n = len(b)
+            host[off:off + n] = np.frombuffer(b, dtype=np.uint8)
+            off += n
+        out = self._dev_payloads[:need]
+        out.copy_(self._pinned[:need], non_blocking=True)
+        self._pinned_free = torch.cuda.Event()
+        self._pinned_free.record(torch.cuda.current_stream(dev))
+        return out
+
+    def _plan(self, lens, amp, flags, pilot_mode, start):
+        ctx = self._ctx
+        if np.all(lens == lens[0]):
+            key = (len(lens), int(lens[0]), float(amp), int(flags), int(pilot_mode), int(start))
+            plan = self._plans.get(key)
+            if plan is None:
+                plan = ctx.plan_uniform(len(lens), int(self._regime), int(lens[0]), symbol_time=self._symbol_time,
+                                        pilot_mode=pilot_mode, pilot_start=start, flags=flags, amp=amp)
+                self._plans[key] = plan
+                if len(self._plans) > 256:
+                    self._plans.popitem(last=False)
+            return plan
+        return ctx.plan_ragged(np.full(len(lens), int(self._regime), np.uint8), lens,
+                               symbol_time=self._symbol_time, pilot_mode=pilot_mode, pilot_start=start,
+                               flags=flags, amp=amp)
+
     def _flush(self):
         if not self._pending:
             return
         pk, self._pending = self._pending, []
-        ctx = self._ctx
-        amp = float(self._gain.k()) if self._gain is not None else 1.0
-        flags = (getattr(self.preamble, "flags", _lib.F_PREAMBLE) | _lib.F_ZEROGAP |
-                 (_lib.F_SWAPIQ if self._swap else 0))
+        framing = getattr(self.preamble, "flags", _lib.F_PREAMBLE) | _lib.F_ZEROGAP
+        flags = framing | (_lib.F_SWAPIQ if self._swap else 0)
         pilot_mode = getattr(self.pilot, "pilot_mode", _lib.PILOT_REF_STREAM)
         lens = np.fromiter((len(p) for p in pk), dtype=np.uint32, count=len(pk))
         start = _pilot_offset[0] % 127
-
-        def make_plan(a):
-            if np.all(lens == lens[0]):
-                return ctx.plan_uniform(len(pk), int(self._regime), int(lens[0]), symbol_time=self._symbol_time,
-                                        pilot_mode=pilot_mode, pilot_start=start, flags=flags, amp=a)
-            return ctx.plan_ragged(np.full(len(pk), int(self._regime), np.uint8), lens,
-                                   symbol_time=self._symbol_time, pilot_mode=pilot_mode, pilot_start=start,
-                                   flags=flags, amp=a)
-
-        plan = make_plan(amp)
-        _pilot_offset[0] += plan.n_symbols
-        host = torch.frombuffer(bytearray(b"".join(pk)) or bytearray(1), dtype=torch.uint8)
-        payloads = host.to(ctx.device)
+        payloads = self._stage_payloads(pk, int(lens.sum()))
+        live = [payloads]
+        unit = None                  # the path's own output: amplitude 1, no I/Q exchange
         if self._log:
-            # examples/ftw_ofdm.py:181-189: of the per-block taps only the mapper's symbols exist as
-            # data here (everything behind the mapper is fused); the bit-level stages are added
-            taps = plan.encode_bits(payloads, taps=True)
-            iq, mapped = plan.modulate(taps["interleaved"], want_mapped=True)
-            self._tap("ofdm_mapper.dat", mapped)
+            # examples/ftw_ofdm.py:181-189: one file per block, named and shaped as there; all taps sit
+            # in front of tx_amplitude and of the I/Q exchange.  The bit-level stages of send_pkt are added.
+            p1 = self._plan(lens, 1.0, framing, pilot_mode, start)
+            bits = p1.encode_bits(payloads, taps=True)
+            unit, front = p1.modulate(bits["interleaved"], taps=True)
+            back = p1.symbol_taps(unit)
+            self._tap("ofdm_mapper.dat", front["mapped"])
+            self._tap("ofdm_pilot.dat", front["pilot"])
+            self._tap("ofdm_cmap.dat", front["cmap"])
+            self._tap("ofdm_ifft.dat", back["ifft"])
+            self._tap("ofdm_cp_adder.dat", back["cp"])
+            self._tap("ofdm_scale.dat", back["scale"])
+            self._tap("ofdm_preamble.dat", back["preamble"])
+            self._tap("ofdm_zerogap.dat", unit)
             for k in ("plcp", "scrambled", "coded", "interleaved"):
-                self._tap("ofdm_%s.dat" % k, taps[k])
-            # output of the last block of the path, i.e. before tx_amplitude (examples/ftw_ofdm.py:189)
-            self._tap("ofdm_zerogap.dat", iq if amp == 1.0 else make_plan(1.0).tx(payloads))
-        else:
-            iq = plan.tx(payloads)
-        for s in self._sinks:
-            s.write(iq)
-        self.last_iq = iq
+                self._tap("ofdm_%s.dat" % k, bits[k])
+            live.append(p1)
+        # one kernel launch per distinct amplitude among the connections (the amplitude is folded
+        # into the transform's twiddles, examples/ftw_ofdm_tx_uhd.py:82-86)
+        done = {}
+        n_symbols = None
+        for gain, sink in (self._outs or [(None, None)]):
+            amp = float(gain.k()) if gain is not None else 1.0
+            if amp not in done:
+                if amp == 1.0 and unit is not None and not self._swap:
+                    done[amp] = unit
+                else:
+                    plan = self._plan(lens, amp, flags, pilot_mode, start)
+                    done[amp] = plan.tx(payloads)
+                    n_symbols = plan.n_symbols
+                    live.append(plan)
+            if sink is not None:
+                sink.write(done[amp])
+        if n_symbols is None:
+            n_symbols = live[-1].n_symbols
+        _pilot_offset[0] += n_symbols
+        self.last_iq = next(iter(done.values()))
+        self._live = live            # the previous flush's plans and buffers may go now: this one is enqueued behind them
 
 
 class ftw_transmit_path(gr.hier_block2):

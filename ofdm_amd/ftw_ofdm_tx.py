@@ -30,6 +30,8 @@ class my_top_block(gr.top_block):
         self._tx_amplitude = options.tx_amplitude
         self.amp = gr.multiply_const_cc(self._tx_amplitude)
         self.connect(self.txpath, self.amp, self.sink)
+        if getattr(options, "log", False):                  # ftw_ofdm_tx_uhd.py:88-89: the path's output in front of tx_amplitude
+            self.connect(self.txpath, gr.file_sink(gr.sizeof_gr_complex, 'ftw_benchmark.dat'))
 
 
 def make_parser():

@@ -173,12 +173,10 @@ class file_source(object):
         if itemsize != sizeof_gr_complex:
             raise ValueError("only complex64 streams are replayed")
         self.filename, self._chunk, self._device = filename, int(chunk_items), device
-        self._gain, self._sinks = None, []
+        self._outs = []              # (multiply_const_cc or None, sink) per connection
 
     def _attach(self, gain, sinks):
-        if gain is not None:
-            self._gain = gain
-        self._sinks.extend(sinks)
+        self._outs.extend((gain, s) for s in sinks)
 
     def _start(self):
         pass
@@ -189,7 +187,6 @@ class file_source(object):
         from . import _lib
         from .ftw_packet_utils import _context
         ctx = _context(self._device)
-        k = complex(self._gain.k()) if self._gain is not None else 1.0 + 0j
         with open(self.filename, "rb") as f:
             while True:
                 host = np.fromfile(f, dtype=np.complex64, count=self._chunk)
@@ -197,10 +194,14 @@ class file_source(object):
                     break
                 dev = torch.from_numpy(host).to(ctx.device)
                 stream = C.c_void_p(torch.cuda.current_stream(ctx.device).cuda_stream)
-                _lib.check(ctx._lib.ofdmtx_scale_cc(ctx._h, C.c_void_p(dev.data_ptr()), dev.numel(), k.real, k.imag,
-                                                    C.c_void_p(dev.data_ptr()), stream))
-                for s in self._sinks:
-                    s.write(dev)
+                for gain, sink in self._outs:
+                    out = dev
+                    if gain is not None:
+                        k = complex(gain.k())
+                        out = torch.empty_like(dev)
+                        _lib.check(ctx._lib.ofdmtx_scale_cc(ctx._h, C.c_void_p(dev.data_ptr()), dev.numel(), k.real,
+                                                            k.imag, C.c_void_p(out.data_ptr()), stream))
+                    sink.write(out)
 
 
 class null_sink(object):
@@ -229,6 +230,32 @@ class vector_sink_c(object):
 
     def close(self):
         pass
+
+
+class vector_source_c(object):
+    """gr.vector_source_c(data, repeat, vlen): items of vlen complex values; with repeat the data
+    starts over when it runs out (rawofdm/examples/ofdm_rxtx.py:120)."""
+
+    def __init__(self, data, repeat=False, vlen=1):
+        self.vlen = int(vlen)
+        d = np.ascontiguousarray(np.asarray(data, dtype=np.complex64).reshape(-1))
+        if d.size % self.vlen:
+            raise ValueError("vector_source_c: data is not a whole number of items")
+        self._data, self._repeat, self._pos, self._dev = d.reshape(-1, self.vlen), bool(repeat), 0, None
+
+    def take(self, n_items, device=None):
+        """The next n_items items (fewer at the end of a non-repeating source) as a flat tensor."""
+        import torch
+        n_have = self._data.shape[0]
+        if not self._repeat:
+            n_items = min(int(n_items), n_have - self._pos)
+        if n_have == 0 or n_items <= 0:
+            return torch.zeros(0, dtype=torch.complex64, device=device)
+        if self._dev is None or (device is not None and self._dev.device != torch.device(device)):
+            self._dev = torch.from_numpy(self._data).to(device if device is not None else "cpu")
+        idx = (torch.arange(self._pos, self._pos + n_items, device=self._dev.device) % n_have)
+        self._pos = (self._pos + n_items) % n_have if self._repeat else self._pos + n_items
+        return self._dev.index_select(0, idx).reshape(-1)
 
 
 class multiply_const_cc(object):
@@ -261,6 +288,9 @@ class top_block(hier_block2):
 
     def connect(self, *blocks):
         src = blocks[0]
+        if hasattr(src, "take") and len(blocks) == 2 and hasattr(blocks[1], "_set_source"):
+            blocks[1]._set_source(src)           # data source -> transmit path (rawofdm/examples/ofdm_tx.py:51)
+            return
         if not hasattr(src, "_attach"):
             raise TypeError("the first block of a connection must be a transmit path")
         gain = None

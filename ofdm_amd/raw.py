@@ -16,91 +16,132 @@ from . import _lib
 from .batch import TxContext, _ptr, _stream
 
 
+def _even_up(n):
+    """Smallest even integer >= n."""
+    n = int(math.ceil(n))
+    return n + (n & 1)
+
+
 class ofdm_params(object):
-    """rawofdm/src/python/raw_ofdm_params.py:13-99: same attributes, same values.
+    """Carrier layout and preamble symbols of the variable-size modulator: the attributes and
+    values of rawofdm/src/python/raw_ofdm_params.py:13-99, derived with index arithmetic.
+
+    Layout of the fft_length bins (DC in the middle, raw_ofdm_params.py:20-22): `pad` unused bins,
+    occupied/2 carriers, DC (null), occupied/2 carriers, pad - 1 unused bins.  With m = 1 ..
+    occupied/2 counting outwards from the band edge towards DC on either side, carriers with
+    m - 1 = 5, 18, 31, ... are pilots (:81-85), the layout is mirrored about DC (:88).
+    Preamble symbols: unit-modulus values exp(2 pi j u) on every occupied carrier, u taken in
+    ascending carrier order, symbol after symbol, from ONE stream random.Random(9817) -- the stream
+    random.seed(9817) gives the reference (:29-37,61-62); the first symbol keeps only even bins,
+    times sqrt(2), when half_sync is set (:39-48,64-67), otherwise it is sent twice (:71-73).
 
     options needs fft_length, occupied_tones, cp_length, num_preambles, half_sync (and may have
     verbose)."""
 
-    def pad_symbol(self, symbol):
-        padded = self.fft_length * [0, ]
-        padded[self.pad: self.pad + self.occupied_tones + 1] = symbol
-        return padded
-
-    def random_symbol(self):
-        # unit-modulus random phases, null at DC (raw_ofdm_params.py:29-37)
-        symbol = [cmath.exp(1j * 2 * math.pi * random.random()) for _ in range(self.occupied_tones)]
-        half = self.occupied_tones // 2
-        return symbol[:half] + [0] + symbol[half:]
-
-    def make_even(self, symbol):
-        # only even absolute bins, boosted to keep the symbol power (raw_ofdm_params.py:39-48)
-        sf = math.sqrt(2)
-        for i in range(len(symbol)):
-            if (self.pad + i) & 1:
-                symbol[i] = 0
-            else:
-                symbol[i] *= sf
-
     def __init__(self, options):
-        self.fft_length = int(math.ceil(options.fft_length / 2.0) * 2)
-        self.occupied_tones = int(math.ceil(options.occupied_tones / 2.0) * 2)
+        n_fft = _even_up(options.fft_length)
+        n_occ = _even_up(options.occupied_tones)                    # without DC
+        half = n_occ // 2
+        self.fft_length = n_fft
         self.cp_length = options.cp_length
         self.num_preambles = options.num_preambles
-        self.pad = (self.fft_length - self.occupied_tones) // 2
-
-        random.seed(9817)                                           # raw_ofdm_params.py:61
-        preambles = [self.random_symbol() for _ in range(options.num_preambles + 1)]
         self.half_sync = options.half_sync
+        self.pad = (n_fft - n_occ) // 2
+        window = slice(self.pad, self.pad + n_occ + 1)              # occupied bins, DC included
+        not_dc = np.arange(n_occ + 1) != half
+
+        # ---- preamble symbols: all phases in one draw, in the reference's order
+        n_pre = int(options.num_preambles) + 1
+        stream = random.Random(9817)
+        phases = [stream.random() for _ in range(n_pre * n_occ)]
+        table = np.zeros((n_pre, n_occ + 1), dtype=complex)
+        table[:, not_dc] = np.array([cmath.exp(2j * math.pi * u) for u in phases]).reshape(n_pre, n_occ)
         if self.half_sync:
-            self.make_even(preambles[0])
-        self.preambles = preambles
-        if not self.half_sync:
-            preambles = [preambles[0]] + preambles
-        self.padded_preambles = [self.pad_symbol(p) for p in preambles]
+            odd_bin = ((self.pad + np.arange(n_occ + 1)) & 1).astype(bool)
+            table[0, odd_bin] = 0
+            table[0, ~odd_bin] *= math.sqrt(2)
+        self.preambles = table.tolist()
+        sent = table if self.half_sync else np.concatenate([table[:1], table])
+        padded = np.zeros((len(sent), n_fft), dtype=complex)
+        padded[:, window] = sent
+        self.padded_preambles = padded.tolist()
 
-        half = self.occupied_tones // 2
-        carriers = half * [1, ]
-        num_pilots = 0
-        for i in range(5, half, 13):                                # raw_ofdm_params.py:81-85
-            carriers[i] = 2
-            num_pilots += 1
-        carriers.extend([0] + list(reversed(carriers)))
-        self.carriers = carriers
-        padded_carriers = self.fft_length * [0, ]
-        padded_carriers[self.pad: self.pad + self.occupied_tones + 1] = carriers
-        self.padded_carriers = padded_carriers
-        self.pilot_tones = num_pilots * 2
-        self.data_tones = self.occupied_tones - self.pilot_tones
-        self.occupied_tones += 1                                    # "include DC" (raw_ofdm_params.py:98-99)
+        # ---- carrier map: 1 data, 2 pilot, 0 unused
+        side = np.ones(half, dtype=int)
+        side[5::13] = 2
+        carriers = np.concatenate([side, [0], side[::-1]])
+        self.carriers = carriers.tolist()
+        padded_map = np.zeros(n_fft, dtype=int)
+        padded_map[window] = carriers
+        self.padded_carriers = padded_map.tolist()
+        self.pilot_tones = int((carriers == 2).sum())
+        self.data_tones = int((carriers == 1).sum())
+        self.occupied_tones = n_occ + 1                             # sizes downstream count DC (:98-99)
         if getattr(options, "verbose", False):
-            self._print_verbage()
+            self._report()
 
-    def _print_verbage(self):
-        from sys import stderr
-        print("\nRaw OFDM parameters:", file=stderr)
-        print("FFT length:      %3d" % self.fft_length, file=stderr)
-        print("Occupied Tones:  %3d (with DC)" % self.occupied_tones, file=stderr)
-        print("Pilot Tones:     %3d" % self.pilot_tones, file=stderr)
-        print("Data Tones:      %3d" % self.data_tones, file=stderr)
-        print("CP length:       %3d" % self.cp_length, file=stderr)
-        print("Extra Preambles: %3d" % self.num_preambles, file=stderr)
+    def _report(self):
+        import sys
+        sys.stderr.write("\nRaw OFDM parameters:\n" + "".join("%-16s %3d%s\n" % row for row in (
+            ("FFT length:", self.fft_length, ""), ("Occupied Tones:", self.occupied_tones, " (with DC)"),
+            ("Pilot Tones:", self.pilot_tones, ""), ("Data Tones:", self.data_tones, ""),
+            ("CP length:", self.cp_length, ""), ("Extra Preambles:", self.num_preambles, ""))))
+
+    _OPTIONS = (  # name, default, what it sets (names and defaults of raw_ofdm_params.py:104-119)
+        ("--fft-length", 64, "FFT size N (bins per OFDM symbol)"),
+        ("--occupied-tones", 52, "carriers in use, DC not counted"),
+        ("--cp-length", 16, "cyclic prefix, in samples"),
+        ("--num-preambles", 2, "preamble symbols behind the synchronisation symbol"),
+    )
 
     @staticmethod
     def add_options(normal, expert):
-        """Same option names and defaults as raw_ofdm_params.py:104-119 (optparse groups)."""
-        expert.add_option("", "--fft-length", type="int", default=64,
-                          help="set the number of FFT bins [default=%default]")
-        expert.add_option("", "--occupied-tones", type="int", default=52,
-                          help="set the number of occupied FFT bins [default=%default]")
-        expert.add_option("", "--cp-length", type="int", default=16,
-                          help="set the number of bits in the cyclic prefix [default=%default]")
-        expert.add_option("", "--num-preambles", type="int", default=2,
-                          help="number of extra preamble symbols [default=%default]")
-        expert.add_option("", "--half-sync", action="store_true", default=True,
-                          help="use two-halves symbol for sync [default]")
+        for name, default, what in ofdm_params._OPTIONS:
+            expert.add_option("", name, type="int", default=default, help=what + " [default=%default]")
+        expert.add_option("", "--half-sync", action="store_true", dest="half_sync", default=True,
+                          help="synchronisation symbol with two equal halves (even bins only) [default]")
         expert.add_option("", "--full-sync", action="store_false", dest="half_sync", default=True,
-                          help="use full symbol for sync")
+                          help="full synchronisation symbol, sent twice")
+
+
+class ofdm_mapper(object):
+    """raw.ofdm_mapper(carrier_map) (rawofdm/src/lib/ofdm/raw_ofdm.i:18-20,
+    rawofdm/src/lib/ofdm/raw_ofdm_mapper.cc:22-80): per OFDM symbol the data values go to the
+    carriers marked 1 in ascending order, the carriers marked 2 carry +1, -1, +1, ... (the same in
+    every symbol), everything else is zero.  In ofdm_mod the block is fused into the modulator
+    kernel; on its own, `work` returns its output -- the kernel's `mapped` tap."""
+
+    def __init__(self, carrier_map, ctx=None, device=0):
+        self.carrier_map = [int(c) for c in carrier_map]
+        if any(c not in (0, 1, 2) for c in self.carrier_map):        # raw_ofdm_mapper.cc:37-38
+            raise RuntimeError("raw_ofdm_mapper: carrier_map must include only 0,1,2")
+        self.fft_length = len(self.carrier_map)
+        self.data_tones = self.carrier_map.count(1)
+        self._ctx, self._device = ctx, device
+
+    def work(self, data, enable=None):
+        """data: n x data_tones complex64 (tensor or array).  enable (optional, one flag per symbol):
+        the block skips symbols whose flag is 0 and leaves their output as it was
+        (raw_ofdm_mapper.cc:50-54) -- returned as zeros here.  Returns an n x fft_length tensor."""
+        if self._ctx is None:
+            self._ctx = TxContext(self._device)
+        ctx = self._ctx
+        if not torch.is_tensor(data):
+            data = torch.from_numpy(np.ascontiguousarray(data, dtype=np.complex64))
+        data = data.to(ctx.device).contiguous().reshape(-1)
+        n_sym = data.numel() // max(self.data_tones, 1) if self.data_tones else 0
+        if self.data_tones and data.numel() != n_sym * self.data_tones:
+            raise ValueError("data does not hold whole symbols of %d values" % self.data_tones)
+        # no preamble symbols: the tap of a plan whose frames start nowhere but at symbol 0
+        flags = np.zeros(max(n_sym, 1), np.uint8)
+        flags[0] = 1
+        plan = plan_flags(ctx, self.fft_length, 0, self.carrier_map, np.zeros((0, self.fft_length), np.complex64),
+                          flags[:n_sym])
+        _, mapped = plan.modulate(data, want_mapped=True)
+        if enable is not None:
+            keep = torch.as_tensor(np.asarray(enable, dtype=np.uint8) != 0, device=ctx.device)
+            mapped = mapped * keep[:, None]
+        return mapped
 
 
 class RawPlan(object):

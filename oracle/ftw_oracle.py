@@ -399,10 +399,15 @@ def assemble_ppdu(sym80, amp=0.3, swap_iq=False):
     return s
 
 
-def modulate(msg, regime, pilot_offset=0, amp=0.3, swap_iq=False, preamble=True, zerogap=True, role=None):
+def modulate(msg, regime, pilot_offset=0, amp=0.3, swap_iq=False, preamble=True, zerogap=True, role=None,
+             preamble_table=None, gap_row=None):
     """Mapper message -> per-stage arrays, following the flowgraph of ftw_ofdm.py:175-179.
     role 'A' / 'B': the PNC blocks of ftw_ofdm.py:101-106,133-138,147-149 (pilot and preamble
-    blocks with user 1 / 2; ftw_pnc_zerogap.cc:81-92 appends the same 13 zero rows)."""
+    blocks with user 1 / 2; ftw_pnc_zerogap.cc:81-92 appends the same 13 zero rows).
+    preamble_table (>= 320 samples) / gap_row (80 samples): the block arguments of
+    ftw_ofdm_preamble.cc:79-83 (first four rows of row 0 of the table are emitted) and
+    ftw_zerogap.cc:88-92 (row 0 is emitted 13 times) when they are not the literals of
+    ftw_packet_utils.py:508,510; both are stored as complex64 by the blocks."""
     user = {None: None, "A": 1, "B": 2}[role]
     mapped, flags = ofdm_mapper(msg, regime)
     pil = ofdm_pilot(mapped, pilot_offset, user)
@@ -413,10 +418,17 @@ def modulate(msg, regime, pilot_offset=0, amp=0.3, swap_iq=False, preamble=True,
     t = tables()
     parts = []
     if preamble:
-        parts.append(t.fft_preamble if user is None else pnc_preamble(user))
+        if preamble_table is not None:
+            assert user is None
+            tab = np.asarray(preamble_table).astype(np.complex64).astype(np.complex128)
+            parts.append(tab[:N_PREAMBLE_ROWS * SYM_LEN])
+        else:
+            parts.append(t.fft_preamble if user is None else pnc_preamble(user))
     parts.append(scaled.reshape(-1))
     if zerogap:
-        parts.append(np.zeros(N_GAP_ROWS * SYM_LEN, dtype=np.complex128))
+        row = np.zeros(SYM_LEN, dtype=np.complex128) if gap_row is None else \
+            np.asarray(gap_row).astype(np.complex64).astype(np.complex128)[:SYM_LEN]
+        parts.append(np.tile(row, N_GAP_ROWS))
     # the amplitude block holds its constant as a complex64 (gr.multiply_const_cc)
     s = np.concatenate(parts) * float(np.float32(amp))
     if swap_iq:

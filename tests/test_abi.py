@@ -64,3 +64,18 @@ def test_host_crc_matches_oracle(lib):
     for n in (0, 1, 24, 1524):
         d = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
         assert lib.crc32(d) == o.ftw_crc32(d)
+
+
+def test_update_crc32_is_the_uninverted_register(lib):
+    """ftw/ftw_crc32.cc:33-64: bit-reversed CRC register from the all-ones start, the `crc` argument
+    ignored; ftw_crc32 = that ^ 0xFFFFFFFF (:72-76)."""
+    import zlib
+    from ofdm_amd import ftw
+    rng = np.random.default_rng(2)
+    for n in (0, 1, 5, 100, 1524):
+        d = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        reg = (zlib.crc32(d) ^ 0xFFFFFFFF) & 0xFFFFFFFF              # zlib inverts at the end; undo it
+        want = int("{:032b}".format(reg)[::-1], 2)
+        for seed in (0, 0xFFFFFFFF, 12345):
+            assert ftw.ftw_update_crc32(seed, d) == want
+        assert ftw.ftw_crc32(d) == want ^ 0xFFFFFFFF

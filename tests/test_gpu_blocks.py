@@ -1,0 +1,281 @@
+"""Block arguments and per-block taps of the FTW flowgraph on the GPU, through the C ABI:
+preamble table / gap row passed to ftw.ofdm_preamble / ftw.zerogap, the `--log` files of
+examples/ftw_ofdm.py:181-189 and examples/ftw_ofdm_tx_uhd.py:88-89, the guard on ragged plans and
+the buffer checks of the batch front end.
+
+Bar: pilot / cmap taps bit-exact; ifft / cp / scale / preamble taps and IQ within 1e-5 relative L2
+per row against the float64 oracle.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from ofdm_amd import _lib
+from oracle import ftw_oracle as fo
+
+pytestmark = pytest.mark.gpu
+
+REL_L2_TOL = 1e-5
+
+
+def rel_l2_rows(got, ref, n):
+    got = np.asarray(got).reshape(-1, n).astype(np.complex128)
+    ref = np.asarray(ref).reshape(-1, n)
+    assert got.shape == ref.shape
+    num = np.sqrt((np.abs(got - ref) ** 2).sum(axis=1))
+    den = np.sqrt((np.abs(ref) ** 2).sum(axis=1))
+    zero = den == 0
+    assert np.all(num[zero] == 0)
+    return np.where(zero, 0.0, num / np.where(zero, 1.0, den))
+
+
+class Options(object):
+    def __init__(self, **kw):
+        self.regime, self.bandwidth, self.interp, self.swapIQ, self.log, self.role = "1", 20e6, 5.0, False, False, None
+        self.tx_amplitude, self.to_file, self.from_file, self.tx_freq = 0.3, None, None, None
+        self.__dict__.update(kw)
+
+
+# ------------------------------------------------------------------ preamble table and gap row
+
+@pytest.mark.parametrize("swap", [False, True])
+def test_custom_preamble_table_and_gap_row(swap):
+    """ftw_ofdm_preamble.cc:79-83 emits the table it is handed, ftw_zerogap.cc:88-92 the row it is
+    handed: a random 4 x 80 table and a random non-zero gap row must come out, times the amplitude."""
+    from ofdm_amd.batch import TxContext
+    ctx = TxContext(0)                      # own context: the tables are per-context state
+    rng = np.random.default_rng(21)
+    table = (rng.standard_normal(330) + 1j * rng.standard_normal(330)).astype(np.complex64)   # rows beyond 4 x 80 unused
+    gap = (rng.standard_normal(80) + 1j * rng.standard_normal(80)).astype(np.complex64)
+    ctx.set_preamble(table)
+    ctx.set_gap(gap)
+    n, ln, regime, amp = 7, 211, 4, 0.37
+    payloads = rng.integers(0, 256, n * ln, dtype=np.uint8)
+    flags = _lib.F_PREAMBLE | _lib.F_ZEROGAP | (_lib.F_SWAPIQ if swap else 0)
+    for plan in (ctx.plan_uniform(n, regime, ln, flags=flags, amp=amp),
+                 ctx.plan_ragged(np.full(n, regime, np.uint8), np.full(n, ln, np.uint32), flags=flags, amp=amp)):
+        iq = plan.tx(torch.from_numpy(payloads).to(ctx.device)).cpu().numpy()
+        lay = plan.layout()
+        for i in range(n):
+            enc = fo.encode_bits(payloads[i * ln:(i + 1) * ln].tobytes(), str(regime))
+            ref = fo.modulate(enc["interleaved"], str(regime), int(lay["pilot_base"][i]), amp, swap,
+                              preamble_table=table, gap_row=gap)["iq"]
+            a = int(lay["sample_off"][i])
+            assert rel_l2_rows(iq[a:a + len(ref)], ref, 80).max() <= REL_L2_TOL
+    # back to zeros: the fix-up kernel is skipped again and the gap rows are exact zeros
+    ctx.set_gap(np.zeros(80, np.complex64))
+    iq = ctx.plan_uniform(2, regime, ln).tx(torch.from_numpy(payloads).to(ctx.device)).cpu().numpy()
+    assert np.all(iq.reshape(2, -1)[:, -13 * 80:] == 0)
+    with pytest.raises(ValueError):
+        ctx.set_preamble(table[:319])
+    with pytest.raises(ValueError):
+        ctx.set_gap(gap[:79])
+    ctx.close()
+
+
+def test_blocks_hand_their_tables_to_the_kernel(tmp_path):
+    """The drop-in blocks pass what they hold: ofdm_mod with a preamble / zerogap block built from a
+    different table produces that table (examples/ftw_packet_utils.py:374-392 builds the blocks)."""
+    from ofdm_amd import ftw, ftw_ofdm, gr
+    rng = np.random.default_rng(22)
+    payload = rng.integers(0, 256, 60, dtype=np.uint8).tobytes()
+    table = (rng.standard_normal(320) + 1j * rng.standard_normal(320)).astype(np.complex64)
+    gap = (0.01 * rng.standard_normal(80) + 0j).astype(np.complex64)
+
+    class Mod(ftw_ofdm.ofdm_mod):
+        pass
+
+    # the constructor reads the blocks from ftw_packet_utils.insert_preamble / insert_zerogap
+    from ofdm_amd import ftw_packet_utils as pu
+    orig_pre, orig_gap = pu.fft_preamble, pu.gap_sample
+    pu.fft_preamble, pu.gap_sample = tuple(table.tolist()), tuple(gap.tolist())
+    try:
+        off0 = ftw_ofdm._pilot_offset[0]
+        mod = Mod(Options(regime="3"), payload)
+    finally:
+        pu.fft_preamble, pu.gap_sample = orig_pre, orig_gap
+    sink = gr.vector_sink_c()
+    tb = gr.top_block()
+    tb.connect(mod, gr.multiply_const_cc(0.5), sink)
+    tb.start()
+    mod.send_pkt(payload)
+    mod.send_pkt(eof=True)
+    tb.wait()
+    enc = fo.encode_bits(payload, "3", mod._symbol_time)
+    ref = fo.modulate(enc["interleaved"], "3", off0, 0.5, preamble_table=table, gap_row=gap)["iq"]
+    assert rel_l2_rows(sink.data(), ref, 80).max() <= REL_L2_TOL
+    with pytest.raises(ValueError):
+        ftw.ofdm_preamble(80, 3, [list(table[:100])])
+    with pytest.raises(RuntimeError):
+        ftw.zerogap(64, 3, [list(gap)])
+
+
+# ------------------------------------------------------------------ per-block taps
+
+@pytest.mark.parametrize("regime,role", [(1, None), (4, None), (6, None), (8, None), (7, "A")])
+def test_taps_behind_the_mapper(txctx, regime, role):
+    rng = np.random.default_rng(30 + regime)
+    lens = np.array([0, 37, 400, 1500, 5], dtype=np.uint32)
+    n = len(lens)
+    payloads = rng.integers(0, 256, int(lens.sum()), dtype=np.uint8)
+    flags = _lib.F_PREAMBLE | _lib.F_ZEROGAP | ({None: 0, "A": _lib.F_PNC_A}[role])
+    pilot_mode = _lib.PILOT_REF_STREAM if role is None else _lib.PILOT_PNC_A
+    plan = txctx.plan_ragged(np.full(n, regime, np.uint8), lens, pilot_mode=pilot_mode, pilot_start=9, flags=flags,
+                             amp=1.0)
+    dev_pay = torch.from_numpy(payloads).to(txctx.device)
+    msg = plan.encode_bits(dev_pay)
+    iq, front = plan.modulate(msg, taps=True)
+    back = plan.symbol_taps(iq)
+    torch.cuda.synchronize()
+    assert torch.equal(iq.view(torch.float32), plan.modulate(msg).view(torch.float32))      # the taps change nothing
+    lay = plan.layout()
+    front = {k: v.cpu().numpy() for k, v in front.items()}
+    back = {k: v.cpu().numpy() for k, v in back.items()}
+    off = 0
+    pre_rows = 6 if role else 4
+    for i in range(n):
+        pl = payloads[off:off + int(lens[i])].tobytes()
+        off += int(lens[i])
+        enc = fo.encode_bits(pl, str(regime))
+        ref = fo.modulate(enc["interleaved"], str(regime), int(lay["pilot_base"][i]), 1.0, role=role)
+        so, ns = int(lay["sym_off"][i]), int(lay["n_sym"][i]) + 1
+        for k in ("mapped", "pilot", "cmap"):                     # pure data movement: bit-exact
+            want = ref[k].astype(np.complex64)
+            assert np.array_equal(front[k][so:so + ns].view(np.uint64), want.view(np.uint64)), (k, i)
+        for k, width in (("ifft", 64), ("cp", 80), ("scale", 80)):
+            assert rel_l2_rows(back[k][so:so + ns], ref[k], width).max() <= REL_L2_TOL, (k, i)
+        p0 = so + i * pre_rows
+        want = ref["iq"][:(pre_rows + ns) * 80]
+        assert rel_l2_rows(back["preamble"][p0:p0 + pre_rows + ns], want, 80).max() <= REL_L2_TOL
+    # the taps need the path's own amplitude
+    with pytest.raises(ValueError):
+        txctx.plan_uniform(1, regime, 10, amp=0.3).symbol_taps(torch.zeros(80 * 40, dtype=torch.complex64, device=txctx.device))
+
+
+def test_log_files_of_the_flowgraph(txctx, tmp_path, monkeypatch):
+    """`--log`: every file of examples/ftw_ofdm.py:181-189 plus ftw_benchmark.dat
+    (examples/ftw_ofdm_tx_uhd.py:88-89), with the reference's names and item sizes, byte-compatible
+    with a gr.file_sink of those streams (raw little-endian complex64)."""
+    from ofdm_amd import ftw_ofdm, ftw_ofdm_tx
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.default_rng(6)
+    payload = rng.integers(0, 256, 120, dtype=np.uint8).tobytes()
+    opt = Options(regime="7", bandwidth=20e6, log=True, to_file=str(tmp_path / "out.dat"), swapIQ=True)
+    off0 = ftw_ofdm._pilot_offset[0]
+    tb = ftw_ofdm_tx.my_top_block(opt, payload)
+    tb.start()
+    n_pk = 3
+    for _ in range(n_pk):
+        tb.txpath.send_pkt(payload)
+    tb.txpath.send_pkt(eof=True)
+    tb.wait()
+    refs, off = [], off0
+    for _ in range(n_pk):
+        r = fo.tx_packet(payload, "7", 4.0, pilot_offset=off, amp=1.0)
+        off += r["info"]["N_sym"] + 1
+        refs.append(r)
+    ns = refs[0]["info"]["N_sym"] + 1
+    cat = lambda k: np.concatenate([np.asarray(r[k]).reshape(-1) for r in refs])
+    rd = lambda name: np.fromfile(name, np.complex64)
+    assert np.array_equal(rd("ofdm_mapper.dat").view(np.uint64), cat("mapped").astype(np.complex64).view(np.uint64))
+    assert np.array_equal(rd("ofdm_pilot.dat").view(np.uint64), cat("pilot").astype(np.complex64).view(np.uint64))
+    assert np.array_equal(rd("ofdm_cmap.dat").view(np.uint64), cat("cmap").astype(np.complex64).view(np.uint64))
+    assert rd("ofdm_pilot.dat").size == n_pk * ns * 53 and rd("ofdm_cmap.dat").size == n_pk * ns * 64
+    assert rel_l2_rows(rd("ofdm_ifft.dat"), cat("ifft"), 64).max() <= REL_L2_TOL
+    assert rel_l2_rows(rd("ofdm_cp_adder.dat"), cat("cp"), 80).max() <= REL_L2_TOL
+    assert rel_l2_rows(rd("ofdm_scale.dat"), cat("scale"), 80).max() <= REL_L2_TOL
+    pre = np.concatenate([r["iq"][:(4 + ns) * 80] for r in refs])
+    assert rel_l2_rows(rd("ofdm_preamble.dat"), pre, 80).max() <= REL_L2_TOL
+    assert rel_l2_rows(rd("ofdm_zerogap.dat"), cat("iq"), 80).max() <= REL_L2_TOL
+    # the path's output in front of tx_amplitude, I and Q exchanged as the path was asked to
+    bench = rd("ftw_benchmark.dat")
+    unit = cat("iq")
+    assert rel_l2_rows(bench, unit.imag + 1j * unit.real, 80).max() <= REL_L2_TOL
+    out = rd(str(tmp_path / "out.dat"))
+    assert rel_l2_rows(out, float(np.float32(0.3)) * (unit.imag + 1j * unit.real), 80).max() <= REL_L2_TOL
+
+
+# ------------------------------------------------------------------ guard rails
+
+def test_ragged_plan_on_a_second_stream_while_busy(txctx):
+    """The work counters of a ragged plan are shared by its launches: a launch on another stream
+    while the previous one still runs must be refused, not raced."""
+    rng = np.random.default_rng(40)
+    n = 60000
+    regimes = rng.integers(1, 9, n).astype(np.uint8)
+    lens = rng.integers(200, 1500, n).astype(np.uint32)
+    plan = txctx.plan_ragged(regimes, lens)
+    payloads = torch.zeros(int(lens.sum()), dtype=torch.uint8, device=txctx.device)
+    iq = plan.alloc_iq()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(device=txctx.device)
+    plan.tx(payloads, out=iq)                                   # a few hundred microseconds of work
+    with torch.cuda.stream(side):
+        with pytest.raises(_lib.OfdmTxError) as e:
+            plan.tx(payloads, out=iq)
+    assert e.value.code == _lib.EBUSY
+    plan.tx(payloads, out=iq)                                   # same stream: ordered, always accepted
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        plan.tx(payloads, out=iq)                               # idle plan: any stream
+    torch.cuda.synchronize()
+    # uniform plans have no shared state
+    uni = txctx.plan_uniform(20000, 8, 1500)
+    pay = torch.zeros(uni.payload_bytes, dtype=torch.uint8, device=txctx.device)
+    out = uni.alloc_iq()
+    uni.tx(pay, out=out)
+    with torch.cuda.stream(side):
+        uni.tx(pay, out=out)
+    torch.cuda.synchronize()
+
+
+def test_undersized_or_foreign_buffers_are_refused(txctx):
+    plan = txctx.plan_uniform(4, 8, 100)
+    pay = torch.zeros(plan.payload_bytes, dtype=torch.uint8, device=txctx.device)
+    good = plan.alloc_iq()
+    for bad in (good[:-1], good.view(torch.float32)[:plan.n_samples], good.cpu(), good[::2],
+                torch.zeros(plan.n_samples, dtype=torch.complex128, device=txctx.device)):
+        with pytest.raises(ValueError):
+            plan.tx(pay, out=bad)
+        with pytest.raises(ValueError):
+            plan.modulate(plan.alloc_msg(), out=bad)
+    with pytest.raises(ValueError):
+        plan.tx(pay[:-1])
+    with pytest.raises(ValueError):
+        plan.rx_demod(good[:-1])
+    with pytest.raises(ValueError):
+        plan.rx_demod(good, out=plan.alloc_msg()[:-1])
+    with pytest.raises(ValueError):
+        plan.rx_decode(plan.alloc_msg(), status=torch.zeros(3, dtype=torch.int32, device=txctx.device))
+    with pytest.raises(ValueError):
+        plan.encode_bits(pay, out=plan.alloc_msg()[:-1])
+
+
+def test_two_modulators_keep_their_own_constellations():
+    """The mapper's constellation is an argument of the block instance (ftw/ftw.i:157-163): two
+    ofdm_mod objects with different point sets of one order must not overwrite each other."""
+    from ofdm_amd import ftw_ofdm, gr
+    from ofdm_amd import ftw_packet_utils as pu
+    payload = bytes(range(50))
+    a = ftw_ofdm.ofdm_mod(Options(regime="3"), payload)
+    rot = tuple(complex(c) * 1j for c in pu.gray_const_qpsk)
+    orig = pu.qpsk
+    pu.qpsk = lambda self: rot
+    try:
+        b = ftw_ofdm.ofdm_mod(Options(regime="3"), payload)
+    finally:
+        pu.qpsk = orig
+    outs = []
+    for m in (a, b, a):
+        sink = gr.vector_sink_c()
+        m._outs = [(None, sink)]
+        ftw_ofdm._pilot_offset[0] = 0
+        m.send_pkt(payload)
+        m.send_pkt(eof=True)
+        outs.append(sink.data())
+    assert np.array_equal(outs[0], outs[2])
+    assert not np.array_equal(outs[0], outs[1])
+    enc = fo.encode_bits(payload, "3", a._symbol_time)
+    assert rel_l2_rows(outs[0], fo.modulate(enc["interleaved"], "3", 0, 1.0)["iq"], 80).max() <= REL_L2_TOL

@@ -62,6 +62,54 @@ def test_params_product_mirror_matches_oracle():
             assert getattr(a, k) == getattr(b, k), k
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(fft_length=256, occupied_tones=208, cp_length=64),
+                                dict(fft_length=1024, occupied_tones=832, cp_length=128, num_preambles=1, half_sync=False),
+                                dict(fft_length=63, occupied_tones=51)])
+def test_params_product_structure_from_the_reference_text(kw):
+    """The product's ofdm_params against what rawofdm/src/python/raw_ofdm_params.py states, without
+    the oracle in between: even-rounded sizes (:52-53), DC null at fft_length/2 (:20-22,36-37),
+    mirror symmetry (:88), pilots at range(5, half, 13) from the band edge (:81-85), unit-modulus
+    preamble values from the generator seeded with 9817 in carrier order (:29-37,61-62), even-bin rule
+    with sqrt(2) for the half-sync symbol (:39-48), first symbol repeated otherwise (:71-73)."""
+    import cmath
+    import math
+    import random
+    from ofdm_amd import raw
+    opt = ro.Options(**kw)
+    p = raw.ofdm_params(opt)
+    n = opt.fft_length + (opt.fft_length & 1)
+    occ = opt.occupied_tones + (opt.occupied_tones & 1)
+    half = occ // 2
+    assert (p.fft_length, p.occupied_tones, p.pad) == (n, occ + 1, (n - occ) // 2)
+    dc = p.pad + half
+    assert dc == n // 2
+    cm = np.asarray(p.padded_carriers)
+    assert cm.shape == (n,) and cm[dc] == 0
+    assert np.all(cm[:p.pad] == 0) and np.all(cm[dc + half + 1:] == 0)
+    assert np.array_equal(cm[p.pad:dc], cm[dc + 1:dc + half + 1][::-1])
+    assert list(np.flatnonzero(cm[p.pad:dc] == 2)) == list(range(5, half, 13))
+    assert set(cm[p.pad:dc].tolist()) <= {1, 2}
+    assert p.pilot_tones == 2 * len(range(5, half, 13)) and p.data_tones == occ - p.pilot_tones
+    assert p.carriers == cm[p.pad:dc + half + 1].tolist()
+    # preamble values: the generator's stream, one value per occupied carrier, DC skipped
+    random.seed(9817)
+    n_sym = opt.num_preambles + 1
+    want = np.zeros((n_sym, n), complex)
+    for s_ in range(n_sym):
+        for c in list(range(p.pad, dc)) + list(range(dc + 1, dc + half + 1)):
+            want[s_, c] = cmath.exp(1j * 2 * math.pi * random.random())
+    if opt.half_sync:
+        want[0, 1::2] = 0
+        want[0, 0::2] *= math.sqrt(2)
+    else:
+        want = np.concatenate([want[:1], want])
+    got = np.asarray(p.padded_preambles)
+    assert got.shape == want.shape and np.array_equal(got, want)
+    occupied = np.abs(want[-1]) > 0
+    assert np.allclose(np.abs(got[-1][occupied]), 1.0) and occupied.sum() == occ
+    assert np.asarray(p.preambles).shape == (n_sym, occ + 1)
+
+
 def test_survey_sizes():
     p = ro.OfdmParams(ro.Options(fft_length=256, occupied_tones=208, cp_length=64))
     assert (p.pilot_tones, p.data_tones) == (16, 192)
@@ -399,3 +447,69 @@ def test_gpu_qam_tx_rejects_bad_geometry(txctx):
     tx.framebytes = raw.framebytes((6, (6, 4)), 44 * 16) - 1
     with pytest.raises(_lib.OfdmTxError):
         tx.modulate(b"\x00" * tx.framebytes)
+
+
+# ------------------------------------------------------------------------------ caller surface
+
+@pytest.mark.gpu
+def test_mapper_block_alone(txctx):
+    """raw.ofdm_mapper(carrier_map) (raw_ofdm.i:18-20) on its own: data to the carriers marked 1,
+    alternating +1 / -1 on the carriers marked 2, bit-exact; the constructor's check of the map."""
+    from ofdm_amd import raw
+    rng = np.random.default_rng(12)
+    p = ro.OfdmParams(ro.Options(fft_length=128, occupied_tones=100, cp_length=9))
+    m = raw.ofdm_mapper(p.padded_carriers, ctx=txctx)
+    assert (m.fft_length, m.data_tones) == (128, p.data_tones)
+    data = (rng.standard_normal((11, p.data_tones)) + 1j * rng.standard_normal((11, p.data_tones))).astype(np.complex64)
+    got = m.work(data).cpu().numpy()
+    assert np.array_equal(got.view(np.uint64), ro.mapper(p.padded_carriers, data).view(np.uint64))
+    en = np.array([1, 0, 1, 1, 0, 0, 1, 1, 1, 0, 1], np.uint8)
+    got = m.work(data, en).cpu().numpy()
+    assert np.array_equal(got, ro.mapper(p.padded_carriers, data, en))
+    with pytest.raises(RuntimeError):                      # raw_ofdm_mapper.cc:37-38
+        raw.ofdm_mapper([0, 1, 3, 1])
+
+
+def test_make_data_is_the_reference_generator():
+    """rawofdm/examples/ofdm_rxtx.py:101-121: unit QPSK from random.seed(78532); Python 2's randint
+    is int(random() * 4) on that stream."""
+    import cmath
+    import math
+    import random
+    from ofdm_amd import ofdm_rxtx
+    src = ofdm_rxtx.make_data(48, 5)
+    random.seed(78532)
+    want = np.array([cmath.exp(1j * (math.pi / 4 * (2 * int(random.random() * 4) + 1))) for _ in range(48 * 5)],
+                    dtype=np.complex64)
+    assert src.vlen == 48
+    assert np.array_equal(src.take(5).numpy(), want)
+    assert np.array_equal(src.take(7).numpy(), np.concatenate([want, want])[:7 * 48])      # repeat=True
+    assert np.allclose(np.abs(want), 1.0) and len(set(np.round(want, 3).tolist())) == 4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw,burst,numpkts", [(dict(), 1, 5), (dict(fft_length=256, occupied_tones=208, cp_length=64, size=7), 3, 10)])
+def test_tx_driven_like_sender_thread(txctx, tmp_path, kw, burst, numpkts):
+    """rawofdm/examples/ofdm_tx.py:37-52 + ofdm_rxtx.py:194-215: make_data -> TX, sender_thread sends
+    bursts of frames, then end of stream; the file holds the frames' samples (times --amp)."""
+    from ofdm_amd import gr, ofdm_rxtx
+    opt = ro.Options(**kw)
+    opt.pause, opt.numpkts, opt.burst = 0.0, numpkts, burst
+    tb = gr.top_block()
+    tx = ofdm_rxtx.TX(opt, ctx=txctx, batch_frames=4)      # small batches: several kernel launches per run
+    data = ofdm_rxtx.make_data(tx.params.data_tones, opt.size, None)
+    tb.connect(data, tx)
+    out = str(tmp_path / "tx.dat")
+    tb.connect(tx, gr.multiply_const_cc(0.5), gr.file_sink(gr.sizeof_gr_complex, out))
+    tb.start()
+    sent = ofdm_rxtx.sender_thread(tx, opt).run()
+    tb.wait()
+    assert sent >= numpkts and sent % burst == 0
+    p = ro.OfdmParams(opt)
+    one = data._data.reshape(opt.size, p.data_tones)
+    ref = ro.modulate(p, np.tile(one, (sent, 1)), ro.frame_flags(sent, opt.size)) * 0.5
+    got = np.fromfile(out, np.complex64)
+    err = rel_l2(got, ref, p.fft_length + p.cp_length)
+    assert err.max() <= REL_L2_TOL, err.max()
+    # qa_ofdm.py:65-67: unit transmit power
+    assert abs(np.mean(np.abs(got / 0.5) ** 2) * (p.fft_length / float(p.occupied_tones - 1)) - 1.0) < 0.2
