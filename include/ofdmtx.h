@@ -232,6 +232,26 @@ int ofdmtx_symbol_taps(ofdmtx_ctx *ctx, const ofdmtx_plan *plan, const float *d_
 int ofdmtx_tx(ofdmtx_ctx *ctx, const ofdmtx_plan *plan, const uint8_t *d_payloads,
               uint8_t *d_work, float *d_iq, void *stream);
 
+/* ofdmtx_plan_ragged_device + ofdmtx_tx in one call that allocates nothing (no hipMalloc / hipFree,
+ * no host heap): for callers that cannot allocate -- tight serving loops, harnesses that forbid
+ * it, code that must not disturb the device's memory pools.  It has no counterpart in the reference.
+ * The plan tables (per-packet records, row table, scan columns, work counters) live in a static
+ * device array of the library, one copy per GPU, held until the process ends; hence the fixed
+ * capacity n_pkts <= OFDMTX_STATIC_MAX_PKTS (OFDMTX_ETOOBIG beyond it).  Inputs as for
+ * ofdmtx_plan_ragged_device (device arrays; d_payload_off may be NULL) and ofdmtx_tx.
+ * iq_capacity = complex samples d_iq can hold: if the batch needs more, nothing is written and
+ * OFDMTX_EINVAL is returned with *n_samples set to the need.  *n_samples (may be NULL) receives the
+ * samples written.  The call waits on `stream` once (the plan totals come back to the host) and
+ * returns with the transmit kernel enqueued.  Every call on a GPU uses that GPU's one array: calls
+ * that overlap on one GPU (two host threads, or a second call on another stream before the first
+ * call's kernel has finished) race -- serialise them. */
+#define OFDMTX_STATIC_MAX_PKTS 65536u
+int ofdmtx_tx_ragged_static(ofdmtx_ctx *ctx, uint64_t n_pkts, const uint8_t *d_regimes,
+                            const uint32_t *d_payload_len, const uint64_t *d_payload_off,
+                            double symbol_time, int pilot_mode, uint32_t pilot_start, unsigned flags,
+                            float amp, const uint8_t *d_payloads, float *d_iq, uint64_t iq_capacity,
+                            uint64_t *n_samples, void *stream);
+
 /* ---- single-message stage operators ---------------------------------------------------
  * The per-packet functions of examples/ftw_packet_utils.py, each on ONE byte string in device
  * memory (MSB-first bits), for callers that keep the reference's stage-by-stage call sequence

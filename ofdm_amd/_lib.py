@@ -67,6 +67,8 @@ PROTOTYPES = {
     "ofdmtx_modulate_taps": (C.c_int, [_VP] * 8),
     "ofdmtx_symbol_taps": (C.c_int, [_VP] * 8),
     "ofdmtx_tx": (C.c_int, [_VP] * 6),
+    "ofdmtx_tx_ragged_static": (C.c_int, [_VP, C.c_uint64, _VP, _VP, _VP, C.c_double, C.c_int, C.c_uint32, C.c_uint,
+                                          C.c_float, _VP, _VP, C.c_uint64, C.POINTER(C.c_uint64), _VP]),
     "ofdmtx_scramble": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, _VP, _VP]),
     "ofdmtx_conv_encode": (C.c_int, [_VP, _VP, C.c_uint32, C.c_int, C.c_uint32, _VP, _VP]),
     "ofdmtx_interleave": (C.c_int, [_VP, _VP, C.c_uint32, C.c_int, _VP, _VP]),
@@ -148,4 +150,5 @@ def get_table(which):
     return buf[:n].copy().view(np.complex64)
 
 
+STATIC_MAX_PKTS = 65536
 TABLE_BPSK, TABLE_QPSK, TABLE_QAM16, TABLE_QAM64, TABLE_PREAMBLE = 1, 2, 4, 6, 100

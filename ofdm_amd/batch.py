@@ -131,6 +131,33 @@ class TxContext:
         return TxPlan(self, h, flags)
 
 
+    def tx_ragged_static(self, regimes, payload_len, payloads, out, payload_off=None, symbol_time=4.0,
+                         pilot_mode=_lib.PILOT_REF_STREAM, pilot_start=0,
+                         flags=_lib.F_PREAMBLE | _lib.F_ZEROGAP, amp=0.3):
+        """Ragged batch -> IQ without any allocation (ofdmtx_tx_ragged_static): device tensors in
+        (uint8 regimes, int32 lengths, optional int64 offsets, uint8 payloads), `out` a complex64
+        tensor of the caller's with room for the batch.  At most _lib.STATIC_MAX_PKTS packets.
+        Returns the number of samples written.  Not safe against another such call running on the
+        same GPU at the same time (one static work area per GPU)."""
+        dev = self.device
+        n = regimes.numel()
+        _check_buffer("regimes", regimes, torch.uint8, dev, n)
+        _check_buffer("payload_len", payload_len, torch.int32, dev, n)
+        if payload_off is not None:
+            _check_buffer("payload_off", payload_off, torch.int64, dev, n)
+        _check_buffer("payloads", payloads, torch.uint8, dev, 0)
+        _check_buffer("iq buffer", out, torch.complex64, dev, 0)
+        n_samples = C.c_uint64(0)
+        rc = self._lib.ofdmtx_tx_ragged_static(self._h, n, _ptr(regimes), _ptr(payload_len), _ptr(payload_off),
+                                               float(symbol_time), int(pilot_mode), int(pilot_start), int(flags),
+                                               float(amp), _ptr(payloads), _ptr(out), out.numel(), C.byref(n_samples),
+                                               _stream(dev))
+        if rc == _lib.EINVAL and n_samples.value > out.numel():
+            raise ValueError("iq buffer holds %d samples, the batch needs %d" % (out.numel(), n_samples.value))
+        _lib.check(rc)
+        return int(n_samples.value)
+
+
 class TxPlan:
     """Geometry of one batch (see include/ofdmtx.h, "plans")."""
 

@@ -38,6 +38,30 @@ namespace {
 
 using namespace ofdmtx_detail;
 
+// ---- static work area of ofdmtx_tx_ragged_static --------------------------------------------
+// The plan tables of one ragged batch of up to OFDMTX_STATIC_MAX_PKTS packets, in a file-scope
+// device array: every GPU the library runs on holds its own copy (at its own address, found once
+// per context with hipGetSymbolAddress) until the process ends.  Host code never uses the array's
+// name as an address -- only the pointer ofdmtx_create stored in the context.
+constexpr size_t up256(size_t v) { return (v + 255u) & ~(size_t)255u; }
+constexpr int PLAN_COLS = 5;          // scanned per packet: payload bytes, PLCP stride, message stride, symbols, rows
+constexpr int SCAN_ITEMS = 8;         // per thread
+constexpr int SCAN_BLOCK = 256 * SCAN_ITEMS;
+struct StaticLayout {
+    static constexpr size_t N = OFDMTX_STATIC_MAX_PKTS;
+    static constexpr size_t n_blocks = (N + 1 + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    static constexpr size_t recs = 0;
+    static constexpr size_t row_start = recs + up256(N * sizeof(PktRec));
+    static constexpr size_t counters = row_start + up256((N + 1) * sizeof(uint32_t));     // a 256-byte line of its own
+    static constexpr size_t plcp_len = counters + 256;
+    static constexpr size_t msg_len = plcp_len + up256(N * sizeof(uint32_t));
+    static constexpr size_t col = msg_len + up256(N * sizeof(uint32_t));
+    static constexpr size_t sums = col + up256(PLAN_COLS * (N + 1) * sizeof(unsigned long long));
+    static constexpr size_t out = sums + up256(PLAN_COLS * n_blocks * sizeof(unsigned long long));
+    static constexpr size_t total = out + 256;
+};
+static __device__ __align__(256) unsigned char g_static_area[StaticLayout::total];    // 6.6 MB
+
 // Work counters of a ragged plan: ctr[0] is the next packet to draw, ctr[1] counts the waves
 // that have left the packet loop.  The last wave out puts both back to zero, so a launch finds
 // the counters as the plan's creation left them and nothing has to be cleared between launches
@@ -1073,10 +1097,6 @@ __host__ __device__ __forceinline__ PktGeom pkt_geometry(const RegimeInfo &ri, i
     return g;
 }
 
-constexpr int PLAN_COLS = 5;          // scanned per packet: payload bytes, PLCP stride, message stride, symbols, rows
-constexpr int SCAN_ITEMS = 8;         // per thread
-constexpr int SCAN_BLOCK = 256 * SCAN_ITEMS;
-
 struct PlanDevOut {                   // totals and maxima read back by the host
     unsigned long long max_plcp_len, max_msg_len, max_n_sym, pay_extent;
     uint32_t error;                   // bit 0: regime outside 1..8, bit 1: payload too long
@@ -1350,6 +1370,8 @@ int ofdmtx_create(int device, ofdmtx_ctx **out)
     if (e == hipSuccess) e = hipMalloc(&c->d_crc, tab.size() * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&c->d_xpow8, xp.size() * sizeof(uint32_t));
     if (e == hipSuccess) e = hipHostMalloc(&c->h_pinned, 256, hipHostMallocDefault);
+    // this device's copy of the static work area (the device is current: hipSetDevice above)
+    if (e == hipSuccess) e = hipGetSymbolAddress(reinterpret_cast<void **>(&c->d_static), HIP_SYMBOL(g_static_area));
     if (e == hipSuccess) e = hipMemcpy(c->d_scr, OFDMTX_SCR_WORD, sizeof(OFDMTX_SCR_WORD), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(c->d_lut, lut, sizeof(lut), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(c->d_pre, OFDMTX_PREAMBLE, sizeof(OFDMTX_PREAMBLE), hipMemcpyHostToDevice);
@@ -1648,6 +1670,88 @@ int ofdmtx_plan_ragged(ofdmtx_ctx *ctx, uint64_t n_pkts, const uint8_t *regimes,
     return OFDMTX_OK;
 }
 
+}  // extern "C" (interrupted: helpers of the device-built plans)
+
+// Device tables of a plan that is built by kernels, wherever they live (allocations of a plan
+// object, or the static work area).
+struct PlanBuildBufs {
+    PktRec *recs;
+    uint32_t *row_start;              // n + 1 entries
+    uint32_t *counters;               // 64 words on a 256-byte line of their own
+    uint32_t *plcp_len, *msg_len;     // n entries each
+    unsigned long long *col;          // PLAN_COLS x (n + 1)
+    unsigned long long *sums;         // PLAN_COLS x n_blocks
+    PlanDevOut *out;
+};
+
+// Enqueues the plan-building kernels on `st` and the copies of the totals into h_out / h_totals
+// (host memory that stays valid until the stream has been synchronised).  Allocates nothing.
+static hipError_t enqueue_plan_build(uint32_t n, const uint8_t *d_regimes, const uint32_t *d_payload_len,
+                                     const uint64_t *d_payload_off, double symbol_time, int pilot_mode,
+                                     uint32_t pilot_start, unsigned flags, const PlanBuildBufs &b, PlanDevOut *h_out,
+                                     unsigned long long *h_totals, hipStream_t st)
+{
+    const size_t pitch = (size_t)n + 1;
+    const uint32_t n_blocks = (uint32_t)((pitch + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    hipError_t e = hipMemsetAsync(b.counters, 0, 256, st);
+    if (e == hipSuccess) e = hipMemsetAsync(b.out, 0, sizeof(PlanDevOut), st);
+    if (e == hipSuccess) e = hipMemsetAsync(b.col, 0, PLAN_COLS * pitch * sizeof(unsigned long long), st);
+    if (e != hipSuccess) return e;
+    if (n)
+        hipLaunchKernelGGL(k_plan_geom, dim3((n + 255u) / 256u), dim3(256), 0, st, n, d_regimes, d_payload_len,
+                           d_payload_off, symbol_time, flags, b.recs, b.plcp_len, b.msg_len, b.col, pitch, b.out);
+    hipLaunchKernelGGL(k_scan_local, dim3(n_blocks, PLAN_COLS), dim3(256), 0, st, b.col, pitch, n, b.sums, n_blocks);
+    hipLaunchKernelGGL(k_scan_sums, dim3(PLAN_COLS), dim3(256), 0, st, b.sums, n_blocks);
+    hipLaunchKernelGGL(k_plan_fill, dim3((n + 1u + 255u) / 256u), dim3(256), 0, st, n, b.col, pitch, b.sums, n_blocks,
+                       d_payload_off ? 1 : 0, pilot_mode, pilot_start, b.recs, b.row_start);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(h_out, b.out, sizeof(PlanDevOut), hipMemcpyDeviceToHost, st);
+    for (int c = 0; c < PLAN_COLS && e == hipSuccess; c++)
+        e = hipMemcpyAsync(&h_totals[c], b.col + c * pitch + n, sizeof(unsigned long long), hipMemcpyDeviceToHost, st);
+    return e;
+}
+
+// Error code for what the plan kernels found, 0 if the batch is fine.
+static int plan_build_verdict(const PlanDevOut &h, const unsigned long long *totals)
+{
+    if (h.error & 1u) return OFDMTX_EREGIME;
+    if (h.error & 2u) return OFDMTX_ELENGTH;
+    if (totals[4] >= 0xFFFFFFF0ull || totals[3] >= 0xFFFFFFF0ull) return OFDMTX_ETOOBIG;
+    return OFDMTX_OK;
+}
+
+// Fills in what the launchers need from the totals and maxima of a device-built plan.
+static void finish_device_plan(ofdmtx_plan *pl, uint64_t n_pkts, bool have_pay_off, const PlanBuildBufs &b,
+                               const PlanDevOut &h, const unsigned long long *totals)
+{
+    // LDS needs of the kernels from the maxima (the same expressions as tx_words_for and friends)
+    ofdmtx_pkt_info worst;
+    memset(&worst, 0, sizeof(worst));
+    worst.plcp_len = (int32_t)h.max_plcp_len;
+    worst.msg_len = (int32_t)h.max_msg_len;
+    worst.n_sym = (int32_t)h.max_n_sym;
+    pl->tx_a_words = tx_words_for(worst) > 16u ? tx_words_for(worst) : 16u;
+    pl->tx_u_words = tx_u_words_for(worst) > 16u ? tx_u_words_for(worst) : 16u;
+    pl->tx_m_words = tx_m_words_for(worst) > 16u ? tx_m_words_for(worst) : 16u;
+    pl->max_sym_rows = (uint32_t)h.max_n_sym + 1u;
+    PlanParams &pp = pl->pp;
+    pp.total_rows = (uint32_t)totals[4];
+    ofdmtx_plan_sizes &sz = pl->sizes;
+    sz.n_pkts = n_pkts;
+    sz.payload_bytes = have_pay_off ? h.pay_extent : totals[0];
+    sz.plcp_bytes = totals[1] + 16;
+    sz.msg_bytes = totals[2] + 16;
+    sz.n_symbols = totals[3];
+    sz.n_rows = totals[4];
+    sz.n_samples = totals[4] * SYM_LEN;
+    pp.recs = b.recs;
+    pp.row_start = b.row_start;
+    pp.next_pkt = b.counters;
+    size_draws(pp, n_pkts, totals[4]);
+}
+
+extern "C" {
+
 int ofdmtx_plan_ragged_device(ofdmtx_ctx *ctx, uint64_t n_pkts, const uint8_t *d_regimes,
                               const uint32_t *d_payload_len, const uint64_t *d_payload_off,
                               double symbol_time, int pilot_mode, uint32_t pilot_start, unsigned flags,
@@ -1661,16 +1765,14 @@ int ofdmtx_plan_ragged_device(ofdmtx_ctx *ctx, uint64_t n_pkts, const uint8_t *d
     ofdmtx_plan *pl = new (std::nothrow) ofdmtx_plan();
     if (!pl) return OFDMTX_ENOMEM;
     plan_common(pl, ctx, n_pkts, pilot_mode, pilot_start, flags, amp);
-    PlanParams &pp = pl->pp;
-    pp.uniform = 0;
+    pl->pp.uniform = 0;
     pl->layout_on_host = false;
     const uint32_t n = (uint32_t)n_pkts;
     hipStream_t st = (hipStream_t)stream;
     const size_t pitch = (size_t)n + 1;
     const uint32_t n_blocks = (uint32_t)((pitch + SCAN_BLOCK - 1) / SCAN_BLOCK);
     const size_t counter_at = (((size_t)n_pkts + 1) * sizeof(uint32_t) + 255u) & ~(size_t)255u;
-    unsigned long long *d_col = nullptr, *d_sums = nullptr;
-    PlanDevOut *d_out = nullptr;
+    PlanBuildBufs b = {};
     PlanDevOut h = {};
     unsigned long long totals[PLAN_COLS] = {};
     hipError_t e = hipEventCreateWithFlags(&pl->busy_ev, hipEventDisableTiming);
@@ -1678,68 +1780,34 @@ int ofdmtx_plan_ragged_device(ofdmtx_ctx *ctx, uint64_t n_pkts, const uint8_t *d
     if (e == hipSuccess) e = hipMalloc(&pl->d_row_start, counter_at + 256);
     if (e == hipSuccess) e = hipMalloc(&pl->d_plcp_len, (n_pkts ? n_pkts : 1) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&pl->d_msg_len, (n_pkts ? n_pkts : 1) * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(&d_col, PLAN_COLS * pitch * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMalloc(&d_sums, (size_t)PLAN_COLS * n_blocks * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMalloc(&d_out, sizeof(PlanDevOut));
-    if (e == hipSuccess) e = hipMemsetAsync(reinterpret_cast<uint8_t *>(pl->d_row_start) + counter_at, 0, 256, st);
-    if (e == hipSuccess) e = hipMemsetAsync(d_out, 0, sizeof(PlanDevOut), st);
-    if (e == hipSuccess) e = hipMemsetAsync(d_col, 0, PLAN_COLS * pitch * sizeof(unsigned long long), st);
+    if (e == hipSuccess) e = hipMalloc(&b.col, PLAN_COLS * pitch * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(&b.sums, (size_t)PLAN_COLS * n_blocks * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(&b.out, sizeof(PlanDevOut));
     if (e == hipSuccess) {
-        if (n)
-            hipLaunchKernelGGL(k_plan_geom, dim3((n + 255u) / 256u), dim3(256), 0, st, n, d_regimes, d_payload_len,
-                               d_payload_off, symbol_time, flags, pl->d_recs, pl->d_plcp_len, pl->d_msg_len, d_col,
-                               pitch, d_out);
-        hipLaunchKernelGGL(k_scan_local, dim3(n_blocks, PLAN_COLS), dim3(256), 0, st, d_col, pitch, n, d_sums, n_blocks);
-        hipLaunchKernelGGL(k_scan_sums, dim3(PLAN_COLS), dim3(256), 0, st, d_sums, n_blocks);
-        hipLaunchKernelGGL(k_plan_fill, dim3((n + 1u + 255u) / 256u), dim3(256), 0, st, n, d_col, pitch, d_sums, n_blocks,
-                           d_payload_off ? 1 : 0, pilot_mode, pp.pilot_start, pl->d_recs, pl->d_row_start);
-        e = hipGetLastError();
+        b.recs = pl->d_recs;
+        b.row_start = pl->d_row_start;
+        b.counters = pl->d_row_start + counter_at / sizeof(uint32_t);
+        b.plcp_len = pl->d_plcp_len;
+        b.msg_len = pl->d_msg_len;
+        e = enqueue_plan_build(n, d_regimes, d_payload_len, d_payload_off, symbol_time, pilot_mode, pl->pp.pilot_start,
+                               flags, b, &h, totals, st);
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(&h, d_out, sizeof(h), hipMemcpyDeviceToHost, st);
-    for (int c = 0; c < PLAN_COLS && e == hipSuccess; c++)
-        e = hipMemcpyAsync(&totals[c], d_col + c * pitch + n, sizeof(unsigned long long), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (d_col) (void)hipFree(d_col);
-    if (d_sums) (void)hipFree(d_sums);
-    if (d_out) (void)hipFree(d_out);
+    if (b.col) (void)hipFree(b.col);
+    if (b.sums) (void)hipFree(b.sums);
+    if (b.out) (void)hipFree(b.out);
     int rc = OFDMTX_OK;
     if (e != hipSuccess) {
         ofdmtx_g_last_hip = (int)e;
         rc = OFDMTX_EHIP;
-    } else if (h.error & 1u) {
-        rc = OFDMTX_EREGIME;
-    } else if (h.error & 2u) {
-        rc = OFDMTX_ELENGTH;
-    } else if (totals[4] >= 0xFFFFFFF0ull || totals[3] >= 0xFFFFFFF0ull) {
-        rc = OFDMTX_ETOOBIG;
+    } else {
+        rc = plan_build_verdict(h, totals);
     }
     if (rc) {
         ofdmtx_plan_destroy(pl);
         return rc;
     }
-    // LDS needs of the kernels from the maxima (the same expressions as tx_words_for and friends)
-    ofdmtx_pkt_info worst;
-    memset(&worst, 0, sizeof(worst));
-    worst.plcp_len = (int32_t)h.max_plcp_len;
-    worst.msg_len = (int32_t)h.max_msg_len;
-    worst.n_sym = (int32_t)h.max_n_sym;
-    pl->tx_a_words = tx_words_for(worst) > 16u ? tx_words_for(worst) : 16u;
-    pl->tx_u_words = tx_u_words_for(worst) > 16u ? tx_u_words_for(worst) : 16u;
-    pl->tx_m_words = tx_m_words_for(worst) > 16u ? tx_m_words_for(worst) : 16u;
-    pl->max_sym_rows = (uint32_t)h.max_n_sym + 1u;
-    pp.total_rows = (uint32_t)totals[4];
-    ofdmtx_plan_sizes &sz = pl->sizes;
-    sz.n_pkts = n_pkts;
-    sz.payload_bytes = d_payload_off ? h.pay_extent : totals[0];
-    sz.plcp_bytes = totals[1] + 16;
-    sz.msg_bytes = totals[2] + 16;
-    sz.n_symbols = totals[3];
-    sz.n_rows = totals[4];
-    sz.n_samples = totals[4] * SYM_LEN;
-    pp.recs = pl->d_recs;
-    pp.row_start = pl->d_row_start;
-    pp.next_pkt = pl->d_row_start + counter_at / sizeof(uint32_t);
-    size_draws(pp, n_pkts, totals[4]);
+    finish_device_plan(pl, n_pkts, d_payload_off != nullptr, b, h, totals);
     *out = pl;
     return OFDMTX_OK;
 }
@@ -1999,6 +2067,58 @@ int ofdmtx_tx(ofdmtx_ctx *ctx, const ofdmtx_plan *pl, const uint8_t *d_payloads,
     HIPCHK(hipSetDevice(ctx->device));
     return launch_tx<false>(ctx, pl, d_payloads, nullptr, nullptr, nullptr, reinterpret_cast<float2 *>(d_iq),
                             (hipStream_t)stream);
+}
+
+// The plan of ofdmtx_plan_ragged_device built into the context's static work area, then the fused
+// kernel on it -- with no allocation on the way: the plan object lives on this stack frame (its
+// vectors stay empty), the totals come back through the context's page-locked words.
+int ofdmtx_tx_ragged_static(ofdmtx_ctx *ctx, uint64_t n_pkts, const uint8_t *d_regimes,
+                            const uint32_t *d_payload_len, const uint64_t *d_payload_off,
+                            double symbol_time, int pilot_mode, uint32_t pilot_start, unsigned flags,
+                            float amp, const uint8_t *d_payloads, float *d_iq, uint64_t iq_capacity,
+                            uint64_t *n_samples, void *stream)
+{
+    if (n_samples) *n_samples = 0;
+    if (!ctx || !ctx->d_static || !ctx->h_pinned) return OFDMTX_EINVAL;
+    if (n_pkts && (!d_regimes || !d_payload_len)) return OFDMTX_EINVAL;
+    if (!plan_modes_ok(pilot_mode, flags)) return OFDMTX_EINVAL;
+    if (n_pkts > OFDMTX_STATIC_MAX_PKTS) return OFDMTX_ETOOBIG;          // the static tables hold no more
+    if (n_pkts == 0) return OFDMTX_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    uint8_t *base = ctx->d_static;                                       // never the array's name: see ofdmtx_create
+    PlanBuildBufs b;
+    b.recs = reinterpret_cast<PktRec *>(base + StaticLayout::recs);
+    b.row_start = reinterpret_cast<uint32_t *>(base + StaticLayout::row_start);
+    b.counters = reinterpret_cast<uint32_t *>(base + StaticLayout::counters);
+    b.plcp_len = reinterpret_cast<uint32_t *>(base + StaticLayout::plcp_len);
+    b.msg_len = reinterpret_cast<uint32_t *>(base + StaticLayout::msg_len);
+    b.col = reinterpret_cast<unsigned long long *>(base + StaticLayout::col);
+    b.sums = reinterpret_cast<unsigned long long *>(base + StaticLayout::sums);
+    b.out = reinterpret_cast<PlanDevOut *>(base + StaticLayout::out);
+    // page-locked landing area: [PlanDevOut][PLAN_COLS totals]
+    static_assert(sizeof(PlanDevOut) + PLAN_COLS * sizeof(unsigned long long) <= 256, "landing area too small");
+    PlanDevOut *h = reinterpret_cast<PlanDevOut *>(ctx->h_pinned);
+    unsigned long long *totals = reinterpret_cast<unsigned long long *>(reinterpret_cast<uint8_t *>(ctx->h_pinned) + 64);
+    static_assert(sizeof(PlanDevOut) <= 64, "landing area layout");
+    // (the memsets inside clear what must start at zero: counters, error word, scan columns -- the
+    //  area keeps the previous call's contents otherwise)
+    hipError_t e = enqueue_plan_build((uint32_t)n_pkts, d_regimes, d_payload_len, d_payload_off, symbol_time, pilot_mode,
+                                      pilot_start % 127u, flags, b, h, totals, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        ofdmtx_g_last_hip = (int)e;
+        return OFDMTX_EHIP;
+    }
+    if (int rc = plan_build_verdict(*h, totals)) return rc;
+    ofdmtx_plan pl;                                                      // transient: no event, no device memory of its own
+    plan_common(&pl, ctx, n_pkts, pilot_mode, pilot_start, flags, amp);
+    pl.pp.uniform = 0;
+    finish_device_plan(&pl, n_pkts, d_payload_off != nullptr, b, *h, totals);
+    if (n_samples) *n_samples = pl.sizes.n_samples;
+    if (pl.sizes.n_samples > iq_capacity) return OFDMTX_EINVAL;
+    if (!d_iq || (!d_payloads && pl.sizes.payload_bytes)) return OFDMTX_EINVAL;
+    return launch_tx<false>(ctx, &pl, d_payloads, nullptr, nullptr, nullptr, reinterpret_cast<float2 *>(d_iq), st);
 }
 
 }  // extern "C"
