@@ -71,6 +71,36 @@ def cpu_baseline(n_sample, threads):
                       "restatement, not GNU Radio" % (n_sample, dt, threads)}
 
 
+def py_refshaped_baseline():
+    """Config 1 (one 1500-byte packet at 6 Mbit/s) through the per-bit pure-Python restatement that keeps
+    the control flow of the reference's send_pkt (oracle/ftw_pybits.py): the order of magnitude of
+    the reference's Python-bound bit chain, one core."""
+    from oracle import ftw_pybits
+    payload = np.random.default_rng(1).integers(0, 256, PAYLOAD, dtype=np.uint8).tobytes()
+    t0 = time.perf_counter()
+    ftw_pybits.encode_bits(payload, "1", 4.0)
+    dt = time.perf_counter() - t0
+    samples = _lib.packet_info(1, PAYLOAD).n_rows * 80
+    return {"value": samples / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": "config 1: one 1500-byte packet at 6 Mbit/s (42 320 samples), bit chain only (no modulation), "
+                      "per-bit Python in the shape of the reference's send_pkt, %.1f ms; restatement, not the "
+                      "reference" % (dt * 1e3)}
+
+
+def host_threads():
+    """Threads for the CPU baseline: every core this job may use.  The scheduler's affinity mask and
+    the thread limit the box exports (OMP_NUM_THREADS: the job's CPU share) bound it; os.cpu_count()
+    is the whole machine, which a one-GPU job does not own."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    share = os.environ.get("OMP_NUM_THREADS", "")
+    if share.isdigit() and int(share) > 0:
+        n = min(n, int(share))
+    return max(1, n)
+
+
 def load_traffic(workload_key):
     """HBM bytes per launch of the named kernel from the committed PMC passes (profiles/), or None."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
@@ -222,8 +252,9 @@ def main():
     ap.add_argument("--raw-cp", type=int, default=64)
     ap.add_argument("--raw-symbols", type=int, default=1 << 20, help="data symbols per GPU per step (rawofdm)")
     ap.add_argument("--gather", type=int, default=0,
-                    help="1: every step also collects all shards' IQ on rank 0 (RCCL send/recv); size --packets so "
-                         "that N shards fit one GPU")
+                    help="1: every step also collects all shards' IQ on rank 0 (config 5: RCCL send/recv, chunk k in "
+                         "flight under the kernels of chunk k + 1); --packets is cut so that N shards fit the root")
+    ap.add_argument("--gather-chunks", type=int, default=8, help="chunks a shard is produced and sent in")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -253,6 +284,11 @@ def main():
         return
     n = a.packets
     info = _lib.packet_info(REGIME, PAYLOAD)
+    gather = bool(a.gather) and world > 1
+    if gather:
+        # the root holds all N shards (48 000 B per packet): at most 60 % of the smaller of HBM size and 288 GB
+        hbm = min(torch.cuda.get_device_properties(dev).total_memory, 288 * 10 ** 9)
+        n = min(n, int(0.6 * hbm / (world * info.n_rows * 640)))
     # packets are sharded by index: rank r holds packets [r*n, (r+1)*n); the stream-wide pilot
     # counter of the reference continues across shards
     pilot_start = (rank * n * (info.n_sym + 1)) % 127
@@ -260,15 +296,28 @@ def main():
     gen = torch.Generator(device=dev)
     gen.manual_seed(2 + rank)
     payloads = torch.randint(0, 256, (n * PAYLOAD,), dtype=torch.uint8, device=dev, generator=gen)
-    msg = plan.alloc_msg()
-    iq = plan.alloc_iq()
+    msg = plan.alloc_msg() if not gather else None
+    iq = plan.alloc_iq() if not gather else None
+    if gather:
+        from ofdm_amd.dist import chunk_bounds, gather_chunked
+        spans = chunk_bounds(n, a.gather_chunks)
+        chunk_plans = [ctx.plan_uniform(hi - lo, REGIME, PAYLOAD,
+                                        pilot_start=(pilot_start + lo * (info.n_sym + 1)) % 127) for lo, hi in spans]
+        gathered = torch.empty(world * plan.n_samples, dtype=torch.complex64, device=dev) if rank == 0 else None
+
+        def produce(k, buf):
+            chunk_plans[k].tx(payloads[spans[k][0] * PAYLOAD:], out=buf)
 
     def step(events=None):
         """One pass of the transmit chain over the batch.  events (start, mid, end) are recorded on
         the launch stream around the kernels."""
         if events is not None:
             events[0].record()
-        if a.fused:
+        if gather:
+            gather_chunked(produce, [p.n_samples for p in chunk_plans], dst=0, out=gathered, device=dev)
+            if events is not None:
+                events[1].record()
+        elif a.fused:
             plan.tx(payloads, out=iq, work=msg)          # k_tx: payload -> IQ in one kernel
             if events is not None:
                 events[1].record()
@@ -279,9 +328,6 @@ def main():
             plan.modulate(msg, out=iq)                   # k_tx, message input
         if events is not None:
             events[2].record()
-        if a.gather and dist:
-            from ofdm_amd.dist import gather_iq
-            gather_iq(iq, dst=0)
 
     dt, evs = timed_steps(step, a, dist, backend, dev)
 
@@ -290,7 +336,7 @@ def main():
 
     # the two-kernel path, outside the timed region, for the per-stage numbers
     stage = None
-    if a.fused and rank == 0 and a.stage_steps > 0:
+    if a.fused and rank == 0 and a.stage_steps > 0 and not gather:
         plan.encode_bits(payloads, out=msg)
         plan.modulate(msg, out=iq)
         ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(a.stage_steps)]
@@ -304,10 +350,32 @@ def main():
         stage = (float(np.mean([e[0].elapsed_time(e[1]) for e in ev])),
                  float(np.mean([e[1].elapsed_time(e[2]) for e in ev])))
 
+    # the fused map + IFFT + CP stage alone: mapper messages -> symbol rows, no preamble / gap rows
+    # (2058 B read + 58 x 640 B written per packet), outside the timed region
+    stage_only = None
+    if a.fused and rank == 0 and a.stage_steps > 0 and not gather:
+        bare = ctx.plan_uniform(n, REGIME, PAYLOAD, pilot_start=pilot_start, flags=0)
+        bare.modulate(msg, out=iq)
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(a.stage_steps)]
+        for e in ev:
+            e[0].record()
+            bare.modulate(msg, out=iq)
+            e[1].record()
+        torch.cuda.synchronize()
+        ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+        sb = n * (info.msg_len + (info.n_sym + 1) * 640)
+        stage_only = {"kernel": "k_tx (message input, flags = 0)", "ms": ms, "bytes_per_packet": info.msg_len + (info.n_sym + 1) * 640,
+                      "GBps": sb / (ms * 1e-3) / 1e9, "frac_of_peak": sb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      "Msamples_per_s": n * (info.n_sym + 1) * 80 / (ms * 1e-3) / 1e6}
+
     if rank == 0:
         samples_per_step = world * plan.n_samples
         value = samples_per_step * a.steps / dt / 1e6
-        if a.fused:
+        if gather:
+            kernel, kernel_ms = "k_tx in chunks + gather to rank 0 (overlapped)", first_ms
+            alg_bytes = n * (PAYLOAD + info.n_rows * 640)
+            kernels = {"k_tx_chunks_and_gather": first_ms}
+        elif a.fused:
             kernel, kernel_ms = "k_tx", first_ms
             alg_bytes = n * (PAYLOAD + info.n_rows * 640)          # payload read + IQ rows written
             kernels = {"k_tx": first_ms}
@@ -326,11 +394,13 @@ def main():
                                    % (n, info.n_sym),
                        "packets_per_gpu": n, "samples_per_packet": info.n_rows * 80,
                        "parallelism": "packets sharded by index over %d GPU(s), %s" % (
-                           world, "IQ gathered on rank 0 every step" if (a.gather and world > 1) else "no collective")},
+                           world, "IQ gathered on rank 0 every step in %d overlapped chunks" % len(spans) if gather else "no collective")},
             "kernel_ms": kernels,
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": load_traffic("%s_54M_1500B_%dpk" % (kernel, n)),
+                         "traffic_source": "profiles/traffic.json (PMC passes of an earlier run of this kernel, "
+                                           "not collected during this run)",
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
         if stage is not None:
@@ -339,9 +409,13 @@ def main():
             out["two_kernel_path"] = {"k_encode_bits_ms": stage[0], "k_tx_msg_ms": stage[1],
                                       "k_tx_msg_GBps": mb / (stage[1] * 1e-3) / 1e9,
                                       "k_tx_msg_frac_of_peak": mb / (stage[1] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if stage_only is not None:
+            out["map_ifft_cp_only"] = stage_only
         if world == 1 and a.cpu_sample > 0:
-            threads = min(16, os.cpu_count() or 1)
+            threads = host_threads()
             out["cpu_baseline"] = cpu_baseline(a.cpu_sample, threads)
+            out["cpu_baseline"]["host_cpu_count"] = os.cpu_count()
+            out["cpu_baseline"]["config1_py_refshaped"] = py_refshaped_baseline()
         print(json.dumps(out), flush=True)
     if dist:
         dist.destroy_process_group()

@@ -68,3 +68,128 @@ def gather_iq(iq, dst=0, group=None):
     if iq.numel():
         dist.send(flat, dst=dst, group=group)
     return None
+
+
+def chunk_bounds(n_pkts, n_chunks):
+    """Packet ranges [lo, hi) of the chunks a shard is produced and sent in (n_chunks >= 1, balanced)."""
+    n_chunks = max(1, min(int(n_chunks), max(int(n_pkts), 1)))
+    return [(n_pkts * k // n_chunks, n_pkts * (k + 1) // n_chunks) for k in range(n_chunks)]
+
+
+def gather_chunked(produce, chunk_samples, dst=0, group=None, out=None, device=None):
+    """Produce this rank's IQ in chunks and collect every rank's chunks on rank `dst`, the transfer of
+    chunk k running under the kernels of chunk k + 1.
+
+    produce(k, buf): enqueue on the CURRENT stream whatever fills `buf` (1-D complex64 tensor of
+    chunk_samples[k] elements on `device`) with chunk k.  chunk_samples: this rank's chunk sizes
+    (ranks may differ).  Returns on `dst` a 1-D complex64 tensor on `device`: all ranks' chunks, rank
+    after rank, chunk after chunk; None on the other ranks.
+
+    Root: its own chunks are produced straight into their place in the result, the peers' chunks are
+    received into place -- one grouped receive per chunk index, so the peers' transfers (each on its
+    own xGMI link to the root) run side by side.  Peers: two chunk buffers; chunk k is sent from a side
+    stream once its kernels have finished while chunk k + 1 is being produced into the other buffer.
+    So a peer never holds more than two chunks, and the root exactly the result.
+    With a backend that cannot move device memory (gloo: the rehearsal of this path on one GPU or on
+    the CPU) device chunks travel through page-locked host buffers; with `device` = cpu there are no
+    streams at all and the same protocol runs on host tensors."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    direct = dist.get_backend(group) == "nccl"           # the backend moves device memory itself
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    device = torch.device(device)
+    gpu = device.type == "cuda"
+    if direct and not gpu:
+        raise ValueError("the nccl backend needs device tensors")
+    sizes_local = [int(c) for c in chunk_samples]
+    sizes_all = [None] * world                           # every rank's chunk sizes (a few integers, once per call)
+    dist.all_gather_object(sizes_all, sizes_local, group=group)
+    compute = torch.cuda.current_stream(device) if gpu else None
+    side = torch.cuda.Stream(device=device) if gpu else None
+
+    def host_buffer(n_floats):
+        return torch.empty(n_floats, dtype=torch.float32, pin_memory=gpu)
+
+    if rank == dst:
+        starts, total = [], 0
+        for r in range(world):
+            row = []
+            for c in sizes_all[r]:
+                row.append(total)
+                total += c
+            starts.append(row)
+        if out is None:
+            out = torch.empty(total, dtype=torch.complex64, device=device)
+        elif out.numel() < total or out.dtype != torch.complex64 or not out.is_contiguous() or out.device != device:
+            raise ValueError("gather buffer must be contiguous complex64 on %s with >= %d samples" % (device, total))
+        flat = torch.view_as_real(out).reshape(-1)
+        piece = lambda r, k: flat[2 * starts[r][k]:2 * (starts[r][k] + sizes_all[r][k])]
+        reqs, staged = [], []
+        for k in range(max(len(c) for c in sizes_all)):
+            # the receives of chunk k from every peer, posted before the root's own chunk k is
+            # produced so that they proceed under its kernels
+            ops = []
+            for r in range(world):
+                if r == dst or k >= len(sizes_all[r]) or sizes_all[r][k] == 0:
+                    continue
+                if direct or not gpu:
+                    ops.append(dist.P2POp(dist.irecv, piece(r, k), r, group))
+                else:
+                    h = host_buffer(2 * sizes_all[r][k])
+                    staged.append((h, r, k))
+                    ops.append(dist.P2POp(dist.irecv, h, r, group))
+            if ops and direct:
+                with torch.cuda.stream(side):
+                    reqs.extend(dist.batch_isend_irecv(ops))
+            elif ops:
+                reqs.extend(dist.irecv(op.tensor, src=op.peer, group=group) for op in ops)
+            if k < len(sizes_local) and sizes_local[k]:
+                produce(k, out[starts[dst][k]:starts[dst][k] + sizes_local[k]])
+        for q in reqs:
+            q.wait()
+        for h, r, k in staged:
+            piece(r, k).copy_(h, non_blocking=True)
+        if gpu:
+            compute.wait_stream(side)
+        return out
+
+    # ---- a peer: two chunk buffers, chunk k on its way while chunk k + 1 is produced
+    biggest = max(sizes_local + [1])
+    bufs = [torch.empty(biggest, dtype=torch.complex64, device=device) for _ in range(2)]
+    hosts = [host_buffer(2 * biggest) for _ in range(2)] if (gpu and not direct) else None
+    pending = [None, None]               # per buffer: (request, event) of the send that still reads it
+    for k, n in enumerate(sizes_local):
+        if n == 0:
+            continue
+        b = k & 1
+        if pending[b] is not None:       # the buffer's previous chunk must have left
+            req, ev = pending[b]
+            req.wait()
+            if ev is not None:
+                compute.wait_event(ev)
+        buf = bufs[b][:n]
+        produce(k, buf)
+        flat = torch.view_as_real(buf).reshape(-1)
+        if not gpu:
+            pending[b] = (dist.isend(flat, dst=dst, group=group), None)
+            continue
+        done = torch.cuda.Event()
+        done.record(compute)
+        with torch.cuda.stream(side):
+            side.wait_event(done)
+            if direct:
+                req = dist.isend(flat, dst=dst, group=group)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            else:
+                h = hosts[b][:2 * n]
+                h.copy_(flat, non_blocking=True)
+                side.synchronize()       # gloo reads host memory from the CPU
+                req, ev = dist.isend(h, dst=dst, group=group), None
+        pending[b] = (req, ev)
+    for p in pending:
+        if p is not None:
+            p[0].wait()
+    if gpu:
+        compute.wait_stream(side)
+    return None

@@ -31,6 +31,10 @@ def test_headline_line():
     assert d["config"]["samples_per_packet"] == 6000 and "workload" in d["config"]
     cb = d["cpu_baseline"]
     assert {"value", "unit", "cores", "kind", "sample"} <= set(cb) and cb["kind"] == "port" and cb["value"] > 0
+    assert cb["cores"] >= 1 and cb["host_cpu_count"] >= cb["cores"] and cb["config1_py_refshaped"]["value"] > 0
+    assert d["roofline"]["traffic_source"].startswith("profiles/traffic.json")
+    # the map + IFFT + CP stage alone, priced at message bytes + symbol rows
+    assert d["map_ifft_cp_only"]["bytes_per_packet"] == 2058 + 58 * 640 and d["map_ifft_cp_only"]["ms"] > 0
     # the fused kernel and the two-kernel path were both run
     assert d["kernel_ms"]["k_tx"] > 0 and d["two_kernel_path"]["k_tx_msg_ms"] > 0
 
@@ -43,3 +47,25 @@ def test_secondary_lines(args):
     d = run_bench(*args)
     assert KEYS <= set(d) and ROOF <= set(d["roofline"])
     assert d["value"] > 0 and 0 < d["roofline"]["frac"] < 1 and "workload" in d["config"]
+
+
+@pytest.mark.gpu
+def test_two_rank_gather_line():
+    """bench.py --gpus 2 --gather 1 the way the driver launches it, rehearsed on one GPU: two ranks over
+    gloo share the device (BENCH_BACKEND=gloo); the line keeps the N = 1 shape."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "2", "--warmup", "1", "--packets", "4096", "--gather", "1",
+                          "--gather-chunks", "4"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert KEYS <= set(d) and d["n_gpus"] == 2 and d["value"] > 0
+    assert "gathered on rank 0" in d["config"]["parallelism"]

@@ -114,3 +114,59 @@ def test_two_rank_rawofdm_frames_equal_single_stream():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert np.array_equal(got, want)
+
+
+def _chunk_worker(rank, world, port, payloads, regime, n_chunks, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = od.shard_bounds(len(payloads), world, rank)
+        n_sym = [o.get_info(p, regime, 4.0)["N_sym"] for p in payloads]
+        spans = [(lo + a, lo + b) for a, b in od.chunk_bounds(hi - lo, n_chunks)]
+        sizes = [sum(o.n_samples(n_sym[i]) for i in range(a, b)) for a, b in spans]
+
+        def produce(k, buf):
+            a, b = spans[k]
+            off = od.pilot_start_of_shard(sum(n + 1 for n in n_sym[:a]))
+            parts = []
+            for p in payloads[a:b]:
+                r = o.tx_packet(p, regime, 4.0, pilot_offset=off)
+                off += r["info"]["N_sym"] + 1
+                parts.append(r["iq"].astype(np.complex64))
+            buf.copy_(torch.from_numpy(np.concatenate(parts)))
+
+        got = od.gather_chunked(produce, sizes, dst=0, device="cpu")
+        if rank == 0:
+            q.put(got.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_chunk_bounds():
+    for n in (0, 1, 5, 1000):
+        for k in (1, 3, 8, 2000):
+            spans = od.chunk_bounds(n, k)
+            assert spans[0][0] == 0 and spans[-1][1] == n and len(spans) <= max(n, 1)
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(len(spans) - 1))
+
+
+def test_two_rank_chunked_gather_equals_single_stream():
+    """The chunk-overlapped gather (peers send chunk k while producing chunk k + 1, the root receives
+    into place): same result as one stream, chunk counts that do and do not divide the shard."""
+    rng = np.random.default_rng(6)
+    payloads = [rng.integers(0, 256, int(n), dtype=np.uint8).tobytes() for n in rng.integers(0, 200, 11)]
+    regime = "6"
+    want = o.tx_stream(payloads, regime).astype(np.complex64)
+    for n_chunks in (1, 3, 4):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_chunk_worker, args=(r, 2, port, payloads, regime, n_chunks, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        got = q.get(timeout=120)
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        assert np.array_equal(got, want), n_chunks
