@@ -372,9 +372,11 @@ int ofdmtx_raw_qam_tx(ofdmtx_ctx *ctx, int qambits, int nc, int np, uint32_t nca
  * values passing through memory (the flow of rawofdm/examples/ofdm_rxtx.py:63-87: qam_tx into
  * ofdm_mod).  `plan` must come from ofdmtx_raw_plan_frames; its frame_size is the bit chain's
  * nsymbols and its data_tones the bit chain's ncarriers (a multiple of 16 here).  d_bytes:
- * n_frames * framebytes bytes; d_iq as for ofdmtx_raw_modulate, 16-byte aligned.  OFDMTX_ESHAPE
- * for geometries or rates this kernel does not take (fft_length 1024, carrier counts off the 16
- * grid, rates outside the table of rawofdm/src/python/raw_qam.py:19-28): run the two calls instead. */
+ * n_frames * framebytes bytes (less than 2 GiB); d_iq as for ofdmtx_raw_modulate, 16-byte aligned.
+ * OFDMTX_ESHAPE for geometries or rates this kernel does not take (carrier counts off the 16 grid,
+ * rates outside the table of rawofdm/src/python/raw_qam.py:19-28, and its entry (1, (6, 4)) -- marked
+ * "DONT USE" there -- whose groups of 16 carriers do not start on byte boundaries): run the two calls
+ * instead. */
 int ofdmtx_raw_tx(ofdmtx_ctx *ctx, const ofdmtx_raw_plan *plan, int qambits, int nc, int np,
                   const uint8_t *d_bytes, float *d_iq, void *stream);
 

@@ -14,6 +14,13 @@
 
 #include "ofdm_common.h"
 
+// Section markers in the generated assembly (tools/asm_sections.py); no code is emitted.
+#ifdef OFDMTX_ASM_MARKERS
+#define SEC(name) asm volatile("; SEC " name)
+#else
+#define SEC(name) do { } while (0)
+#endif
+
 namespace {
 
 constexpr uint32_t ROW_DROPPED = 0xFFFFFFFFu;
@@ -108,47 +115,55 @@ constexpr int RAW_WAVES = 4;
 // N=1024: 1.07 against 0.97 ms per 1.05e6 / 2.6e5 symbols); the bit chain's value stores keep sc1 (2-3 % faster).
 constexpr int RAW_ROW_AUX = 0;
 
+// float2 per symbol area: the padded transposition layout M x (L + 1), which also holds the N
+// time-domain samples afterwards (the cyclic prefix is not staged: it is read from the tail again)
+template <int L, int M>
+constexpr int raw_area() { return (M * (L + 1) + 1) & ~1; }
+
 // Steps 1b-3 of the N = L * M point modulator for the S = max(L, M) lanes of one symbol (lane t of
-// the symbol, symbol area T, wave's first area T_wave with SPW areas of TS float2 each):
+// the symbol, symbol area T, wave's first area T_wave with SPW areas of raw_area<L, M>() float2 each):
 //   bin k = l + L m of the (DC-centred) input:  x[M q + p] = sum_l W_L^{l q} W_N^{l p} sum_m X[l + L m] W_M^{m p}
 // On entry lane t < L holds its M bins in x, bit-reversed.  step 1b: M-point transforms in
 // registers, times W_N^{l p} / sqrt(N), to LDS; step 2: lane p < M reads the L partial results,
-// transforms them and puts its samples M q + p, cyclic prefix included, back into the area as one
-// output row; step 3: the wave stores the rows with 16 bytes per lane, consecutive over the lanes.
+// transforms them and puts its samples M q + p back into the area in time order; step 3: the wave
+// stores the rows with 16 bytes per lane, consecutive over the lanes -- output sample i of a row is
+// time sample (i - cp) mod N (gr-digital ofdm_cyclic_prefixer, rawofdm/src/python/raw_ofdm_mod.py:47).
 // All lanes of the wave must call it (wave-level hand-overs inside).
 template <int L, int M>
 __device__ __forceinline__ void raw_transform_store(bool active, int t, int lane, uint32_t row, v2f (&x)[M], v2f *T,
-                                                    const v2f *T_wave, int TS, const v2f *s_tw, uint32_t n, uint32_t cp,
+                                                    const v2f *T_wave, const v2f *s_tw, uint32_t n, uint32_t cp,
                                                     float2 *__restrict__ iq)
 {
-    constexpr int N = L * M, S = L > M ? L : M, SPW = 64 / S;
+    constexpr int N = L * M, S = L > M ? L : M, SPW = 64 / S, TS = raw_area<L, M>();
     const uint32_t row_len = n + cp;
+    SEC("t_fft1");
     if (active && t < L) {
         idft_reg<M>(x);
 #pragma unroll
         for (int p = 0; p < M; p++) T[p * (L + 1) + t] = cmul(x[p], s_tw[(t * p) & (N - 1)]);
     }
     wave_sync();
-    // ---- step 2: L-point transforms, cyclic prefix (gr-digital ofdm_cyclic_prefixer,
-    // rawofdm/src/python/raw_ofdm_mod.py:47)
+    // ---- step 2: L-point transforms
     v2f y[L];
+    SEC("t_fft2");
     if (active && t < M) {
 #pragma unroll
         for (int l = 0; l < L; l++) y[bit_reverse(l, L)] = T[t * (L + 1) + l];
         idft_reg<L>(y);
     }
     wave_sync();                                              // the partial results are consumed
-    if (active && t < M && row != ROW_DROPPED) {
-        const uint32_t tail = n - cp;                         // samples >= tail are repeated in front
+    SEC("t_cp");
+    if (active && t < M) {
 #pragma unroll
-        for (int q = 0; q < L; q++) {
-            const uint32_t k = (uint32_t)(M * q + t);
-            T[cp + k] = y[q];
-            if (k >= tail) T[k - tail] = y[q];
-        }
+        for (int q = 0; q < L; q++) T[M * q + t] = y[q];
     }
     wave_sync();
-    // ---- step 3: rows to memory (a row starts on a 16-byte boundary when row_len is even)
+    // ---- step 3: rows to memory (a row starts on a 16-byte boundary when row_len is even; cp is
+    // even then as well, so a 16-byte piece never straddles the end of the prefix)
+    SEC("t_store");
+    const uint32_t tail = n - cp;                             // first time sample of the prefix
+    // output sample 2 i of a row is time sample (2 i - cp) mod N: the lane's first piece, then 128 samples on
+    const uint32_t k0 = (2u * (uint32_t)lane + tail) & (uint32_t)(N - 1);
 #pragma unroll
     for (int sl = 0; sl < SPW; sl++) {
         const uint32_t row_s = __shfl(row, sl * S);           // the row of slot sl
@@ -156,11 +171,17 @@ __device__ __forceinline__ void raw_transform_store(bool active, int t, int lane
         const v2f *Ts = T_wave + sl * TS;
         float2 *o = iq + (size_t)row_s * row_len;
         if ((row_len & 1u) == 0u) {
-            const float4 *src4 = reinterpret_cast<const float4 *>(Ts);
             const __amdgpu_buffer_rsrc_t win = iq_window(o);
-            for (uint32_t i = lane; i < row_len / 2; i += 64) iq_store<RAW_ROW_AUX>(win, i, src4[i]);
+            uint32_t k = k0;
+            for (uint32_t i = lane; i < row_len / 2; i += 64) {
+                iq_store<RAW_ROW_AUX>(win, i, *reinterpret_cast<const float4 *>(Ts + k));
+                k = (k + 128u) & (uint32_t)(N - 1);
+            }
         } else {
-            for (uint32_t i = lane; i < row_len; i += 64) o[i] = make_float2(Ts[i].x, Ts[i].y);
+            for (uint32_t i = lane; i < row_len; i += 64) {
+                const uint32_t k = i < cp ? tail + i : i - cp;
+                o[i] = make_float2(Ts[k].x, Ts[k].y);
+            }
         }
     }
 }
@@ -176,10 +197,7 @@ template <int L, int M>
 __global__ void __launch_bounds__(64 * RAW_WAVES)
 k_raw_modulate(RawParams R, const float2 *__restrict__ data, float2 *__restrict__ mapped, float2 *__restrict__ iq)
 {
-    constexpr int N = L * M, S = L > M ? L : M, SPW = 64 / S;
-    constexpr int TT = M * (L + 1);                       // float2 per symbol in the transposition area (rows padded by 1)
-    // the area also stages the symbol's output row (N + cp <= 2 N samples), on a 16-byte boundary
-    const int TS = ((TT > (int)(R.n + R.cp) ? TT : (int)(R.n + R.cp)) + 1) & ~1;
+    constexpr int N = L * M, S = L > M ? L : M, SPW = 64 / S, TS = raw_area<L, M>();
     extern __shared__ __align__(16) unsigned char s_raw[];
     v2f *s_tw = reinterpret_cast<v2f *>(s_raw);                            // N
     v2f *s_t = s_tw + N;                                                   // RAW_WAVES * SPW * TS
@@ -249,17 +267,16 @@ k_raw_modulate(RawParams R, const float2 *__restrict__ data, float2 *__restrict_
                 }
             }
         }
-        raw_transform_store<L, M>(active, t, lane, active ? row : ROW_DROPPED, x, T, s_t + wave * SPW * TS, TS, s_tw, R.n,
+        raw_transform_store<L, M>(active, t, lane, active ? row : ROW_DROPPED, x, T, s_t + wave * SPW * TS, s_tw, R.n,
                                   R.cp, iq);
         wave_sync();
     }
 }
 
 template <int L, int M>
-size_t raw_lds_bytes(uint32_t row_len)
+size_t raw_lds_bytes()
 {
-    constexpr int N = L * M, S = L > M ? L : M, SPW = 64 / S, TT = M * (L + 1);
-    const int TS = ((TT > (int)row_len ? TT : (int)row_len) + 1) & ~1;
+    constexpr int N = L * M, S = L > M ? L : M, SPW = 64 / S, TS = raw_area<L, M>();
     return (size_t)N * sizeof(float2) + (size_t)RAW_WAVES * SPW * TS * sizeof(float2) + (size_t)N * sizeof(int16_t);
 }
 
@@ -268,7 +285,7 @@ int launch_raw(const ofdmtx_ctx *ctx, const RawParams &rp, const float2 *data, f
                hipStream_t st)
 {
     constexpr int S = L > M ? L : M, SPW = 64 / S;
-    const size_t lds = raw_lds_bytes<L, M>(rp.n + rp.cp);
+    const size_t lds = raw_lds_bytes<L, M>();
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_raw_modulate<L, M>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint64_t items = ((uint64_t)rp.n_sym + SPW - 1) / SPW + rp.n_frames;
@@ -509,6 +526,79 @@ struct UnitBits {
         }
     }
 
+    // The same pieces without any staging: the QB units of one group of 16 carriers are punctured
+    // bits 16 QB c' .. of the symbol, i.e. a run of IN_BITS = 8 QB NC / NP input bits that starts on a
+    // byte boundary (for every rate of raw_qam.py:19-28 but (1, (6, 4)), marked "DONT USE" there): the
+    // lane fetches those bytes and the byte in front (the encoder's six bits of history), encodes
+    // them itself (raw_conv.cc:46-51) and cuts its pieces out of the two streams.
+    static constexpr int IN_BITS = 8 * QB * NC / NP, IN_BYTES = IN_BITS / 8, IN_WORDS = (IN_BITS + 31) / 32;
+    static constexpr int FULL = (IN_BYTES - 1) / 4, TAIL = IN_BYTES - 4 * FULL;      // dwords in front of the last byte's word
+    // What a lane fetches for one group, untouched (so that nothing waits for the loads before the
+    // values are needed): FULL dwords, the 1..4 bytes of the last word, the byte in front.
+    struct Raw {
+        uint32_t le[FULL > 0 ? FULL : 1];
+        uint32_t tail[TAIL];
+        uint32_t prev;
+    };
+    // p: the group's first input byte; have_prev: the byte in front belongs to the frame (else the
+    // encoder starts from zero); have_last: so does the group's last byte (else it is the frame's
+    // zero padding byte, raw_qam.py:83-85, which need not exist in memory).
+    static __device__ __forceinline__ void fetch(Raw &r, const uint8_t *__restrict__ p, bool have_prev, bool have_last)
+    {
+        static_assert(IN_BITS % 8 == 0, "the group's input must be whole bytes");
+        r.prev = 0;
+        if (have_prev) r.prev = p[-1];
+#pragma unroll
+        for (int j = 0; j < FULL; j++) __builtin_memcpy(&r.le[j], p + 4 * j, 4);      // any alignment
+#pragma unroll
+        for (int i = 0; i < TAIL - 1; i++) r.tail[i] = p[4 * FULL + i];
+        r.tail[TAIL - 1] = 0;
+        if (have_last) r.tail[TAIL - 1] = p[IN_BYTES - 1];
+    }
+    __device__ __forceinline__ void encode(const Raw &r)
+    {
+        uint32_t A[IN_WORDS + 1], Bs[IN_WORDS + 1];
+        uint32_t prev = r.prev;
+#pragma unroll
+        for (int j = 0; j < IN_WORDS; j++) {
+            uint32_t cur;
+            if (j < FULL) {
+                cur = __builtin_bswap32(r.le[j]);
+            } else {
+                cur = 0;
+#pragma unroll
+                for (int i = 0; i < TAIL; i++) cur |= r.tail[i] << (24 - 8 * i);
+            }
+            const uint32_t y1 = __funnelshift_r(cur, prev, 1), y3 = __funnelshift_r(cur, prev, 3);
+            const uint32_t y4 = __funnelshift_r(cur, prev, 4), y5 = __funnelshift_r(cur, prev, 5);
+            const uint32_t y6 = __funnelshift_r(cur, prev, 6);
+            A[j] = cur ^ y3 ^ y4 ^ y5 ^ y6;                       // polynomial 121: u[n], u[n-3..n-6]
+            Bs[j] = cur ^ y1 ^ y3 ^ y4 ^ y6;                      // polynomial 91: u[n], u[n-1], u[n-3], u[n-4], u[n-6]
+            prev = cur;
+        }
+        A[IN_WORDS] = 0;
+        Bs[IN_WORDS] = 0;
+        if constexpr (NC == 4 && NP == 4) {
+#pragma unroll
+            for (int u = 0; u < NPIECE; u++) {
+                a[u] = (A[u >> 2] >> (24 - 8 * (u & 3))) & 0xFFu;
+                b[u] = (Bs[u >> 2] >> (24 - 8 * (u & 3))) & 0xFFu;
+            }
+        } else if constexpr (NC == 6) {
+#pragma unroll
+            for (int u = 0; u < NPIECE; u++) {
+                const int i = (12 * u) >> 5, sh = (12 * u) & 31;
+                a[u] = (sh ? __funnelshift_l(A[i + 1], A[i], sh) : A[i]) >> 20;
+                b[u] = (sh ? __funnelshift_l(Bs[i + 1], Bs[i], sh) : Bs[i]) >> 20;
+            }
+        } else {
+            a[0] = A[0];
+            a[1] = A[1];
+            b[0] = Bs[0];
+            b[1] = Bs[1];
+        }
+    }
+
     template <int U, int B>
     __device__ __forceinline__ uint32_t bit() const                       // bit B of unit U
     {
@@ -542,6 +632,73 @@ __device__ __forceinline__ void emit_unit_group(const UnitBits<QB, NC, NP> &ub, 
                                        (QB == 1 ? 0u : axis_index<QB, NC, NP, S, B, (QB == 1 ? 0 : 1)>(ub, bits{})))), ...);
 }
 
+// ---- the same through look-up tables (rates 1/2 and 3/4; LDS reads instead of a dozen VALU
+// operations per carrier).  Bit position B of the group's units splits as B = 8 h + 2 kk + s: s picks
+// the encoder stream the bit was punctured from, h the half of the unit's piece (a byte at rate 1/2,
+// a 12-bit window at rate 3/4), kk = 0..3 the bit inside that half (at rate 3/4 a half is 6 bits of
+// which positions 0, 1, 3, 4 survive the puncturing).  The 16 index bytes of a group are written as
+// four words (s, h) of four bytes kk.  Unit U = S a + v (axis a, place v in the axis' group of S bits)
+// feeds bit (S - 1 - ((v - B) mod S)) of its axis' index in byte B: for one word that is a fixed
+// function of the half-piece, tabulated per (v, s, h): GROUP_LUT[((v * 2 + s) * 2 + h) << HB | half].
+template <int QB, int NC, int NP>
+struct GroupLut {
+    static constexpr bool USED = !(NC == 4 && NP == 3);
+    static constexpr int S = QB / 2 > 1 ? QB / 2 : 1, HB = NC == 6 ? 6 : 4;
+    // byte kk of word (s, h) takes, from the unit at place v, the bit for index bit S - 1 - ((v - 8 h - s - 2 kk) mod S):
+    // the table depends on (v, s, h) only through the class (v - 8 h - s) mod S
+    static constexpr int WORDS = USED ? S * (1 << HB) : 1;
+    static constexpr int cls(int v, int sbit, int h) { return (((v - 8 * h - sbit) % S) + S) % S; }
+
+    static __device__ __forceinline__ void fill(uint32_t *lut, int tid, int nthr)
+    {
+        if constexpr (USED) {
+            for (int e = tid; e < WORDS; e += nthr) {
+                const int half = e & ((1 << HB) - 1), c = e >> HB;
+                uint32_t w = 0;
+                for (int kk = 0; kk < 4; kk++) {
+                    const int pos = NC == 6 ? 3 * (kk / 2) + kk % 2 : kk;            // MSB-first place inside the half
+                    const int t = (((c - 2 * kk) % S) + S) % S;
+                    w |= (uint32_t)((half >> (HB - 1 - pos)) & 1) << (8 * kk + S - 1 - t);
+                }
+                lut[e] = w;
+            }
+        }
+    }
+
+    // the group's 16 index bytes (four words) from the pieces of its units
+    static __device__ __forceinline__ void emit(const UnitBits<QB, NC, NP> &ub, const uint32_t *lut, uint32_t (&out)[4])
+    {
+        constexpr uint32_t MASK = ((1u << HB) - 1u) << 2;
+#pragma unroll
+        for (int sbit = 0; sbit < 2; sbit++) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                uint32_t axis[2] = {0u, 0u};
+#pragma unroll
+                for (int U = 0; U < (QB == 1 ? 1 : QB); U++) {
+                    const uint32_t piece = sbit ? ub.b[U] : ub.a[U];
+                    // byte offset of the entry: (half-piece) * 4
+                    const uint32_t off = h ? (piece << 2) & MASK : (piece >> (HB - 2)) & MASK;
+                    const int v = U % S, a = U / S;
+                    axis[a] |= *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(lut + (cls(v, sbit, h) << HB)) + off);
+                }
+                out[2 * sbit + h] = (axis[0] << 3) | axis[1];
+            }
+        }
+    }
+
+    // where carrier c of a symbol (c = B G + c') sits in the symbol's index row
+    static __device__ __forceinline__ uint32_t offset_of(uint32_t c, uint32_t G)
+    {
+        if constexpr (USED) {
+            const uint32_t B = c / G, cp = c - B * G;
+            return 16u * cp + 4u * (2u * (B & 1u) + (B >> 3)) + ((B >> 1) & 3u);
+        } else {
+            return c;
+        }
+    }
+};
+
 // LDS areas of one pass of the bit chain (rows = OFDM symbols): staged frame words, coded words,
 // punctured words (the coded ones again at rate 1/2), 4 words of bookkeeping per row.
 struct QamBufs {
@@ -562,25 +719,29 @@ __device__ __forceinline__ void qam_rows_to_punctured(const QamTxParams &Q, cons
                                                       const QamWalks &wk, uint32_t in_per_row)
 {
     constexpr uint32_t PIN = NC == 4 ? 4 : 3, POUT = NC == 4 ? 3 : 2;
-    __syncthreads();                                          // previous rows consumed (and tables written)
-    for (uint32_t rr = threadIdx.x; rr < rows_here; rr += blockDim.x) {
-        // where the row's input starts: frame, first staged byte (4 bytes ahead of the row's
-        // first input bit, may be negative), bit offset of that first input bit in the stage
+    const uint32_t tid0 = threadIdx.x, nthr = blockDim.x;
+    __syncthreads();                                       // previous rows consumed (and tables written)
+    SEC("q_rows");
+    for (uint32_t rr = tid0; rr < rows_here; rr += nthr) {
+        // where the row's input starts: its first staged byte lies 4 bytes ahead of the row's first
+        // input bit -- as an offset into the whole buffer (negative in front of the first frame;
+        // the launchers keep the buffer below 2 GiB, so 32 bits hold it) and inside its frame
         const uint64_t row = row0 + rr, f = row / Q.nsymbols;
         const uint32_t sym = (uint32_t)(row - f * Q.nsymbols);
         const uint32_t n0 = sym * in_per_row;
-        const uint64_t base = f * Q.frame_bytes;
-        B.row[4u * rr + 0] = (uint32_t)base;
-        B.row[4u * rr + 1] = (uint32_t)(base >> 32);
-        B.row[4u * rr + 2] = (n0 >> 3);              // byte of the first input bit (stage starts 4 earlier)
-        B.row[4u * rr + 3] = 32u + (n0 & 7u);        // its bit offset in the stage
+        const int32_t fb0 = (int32_t)(n0 >> 3) - 4;
+        B.row[4u * rr + 0] = (uint32_t)((int32_t)(f * Q.frame_bytes) + fb0);
+        B.row[4u * rr + 1] = (uint32_t)fb0;
+        B.row[4u * rr + 3] = 32u + (n0 & 7u);        // bit offset of the first input bit in the stage
     }
     __syncthreads();
     // ---- stage the frame bytes behind every row, zeros outside the frame (the padding byte
     // of raw_qam.py:85 and the encoder's zero start state), as MSB-first words.  Frames lie back
-    // to back, so a word that straddles a frame boundary is loaded whole (only the ends of the
-    // buffer need a clamped address) and masked; a thread issues all its loads before it uses
-    // the first one.
+    // to back, so a word that straddles a frame boundary is loaded whole and masked; only at the
+    // two ends of the buffer is the 4-byte window moved inside (and the bytes shifted back).  A
+    // thread issues all its loads before it uses the first one.
+    SEC("q_stage");
+    const int32_t last_window = (int32_t)Q.total_bytes - 4;
     for (RowWalk w = wk.in; w.r < rows_here;) {
         constexpr int K = 4;
         uint32_t le[K], lds_at[K], mask[K];
@@ -589,16 +750,16 @@ __device__ __forceinline__ void qam_rows_to_punctured(const QamTxParams &Q, cons
         for (int k = 0; k < K; k++) {
             lds_at[k] = 0xFFFFFFFFu;
             if (w.r < rows_here) {
-                const int64_t fb = (int64_t)B.row[4u * w.r + 2] - 4 + 4 * (int64_t)w.x;    // first of 4 frame bytes
-                const int64_t g = (int64_t)(((uint64_t)B.row[4u * w.r + 1] << 32) | B.row[4u * w.r + 0]) + fb;
-                int64_t gc = g < 0 ? 0 : g;
-                gc = gc > (int64_t)Q.total_bytes - 4 ? (int64_t)Q.total_bytes - 4 : gc;
-                __builtin_memcpy(&le[k], data + gc, 4);       // any alignment
-                shift[k] = 8 * (int)(g - gc);                 // bytes the clamp moved the window by
-                const int64_t lo = fb < 0 ? -fb : 0, hi = (int64_t)Q.frame_bytes - fb < 4 ? (int64_t)Q.frame_bytes - fb : 4;
-                uint32_t m = 0;
-                if (lo < hi) m = (0xFFFFFFFFu >> (8 * (int)lo)) & ~(hi < 4 ? 0xFFFFFFFFu >> (8 * (int)hi) : 0u);
-                mask[k] = m;
+                const int32_t g = (int32_t)B.row[4u * w.r + 0] + 4 * (int32_t)w.x;      // buffer offset of the 4 bytes
+                const int32_t fb = (int32_t)B.row[4u * w.r + 1] + 4 * (int32_t)w.x;     // the same inside the frame
+                const int32_t gc = g < 0 ? 0 : (g > last_window ? last_window : g);
+                __builtin_memcpy(&le[k], data + (uint32_t)gc, 4);                       // any alignment
+                shift[k] = 8 * (g - gc);                      // bytes the window was moved by, as bits
+                // bytes lo .. hi-1 of the four lie inside the frame (byte 0 = most significant after the swap)
+                const int32_t lo = fb < 0 ? (fb < -4 ? 4 : -fb) : 0;
+                const int32_t room = (int32_t)Q.frame_bytes - fb, hi = room > 4 ? 4 : (room < 0 ? 0 : room);
+                const int32_t width = hi - lo;
+                mask[k] = width >= 4 ? 0xFFFFFFFFu : width <= 0 ? 0u : (((1u << (8 * width)) - 1u) << (8 * (4 - hi)));
                 lds_at[k] = w.r * B.in_stride + w.x;
             }
             w.next();
@@ -608,7 +769,8 @@ __device__ __forceinline__ void qam_rows_to_punctured(const QamTxParams &Q, cons
             if (lds_at[k] != 0xFFFFFFFFu) {
                 const uint32_t be = __builtin_bswap32(le[k]);
                 const int sh = shift[k];
-                const uint32_t v = sh >= 32 || sh <= -32 ? 0u : sh > 0 ? be << sh : be >> (-sh);
+                // (|sh| >= 32 only where the mask is zero: the shift count may wrap)
+                const uint32_t v = sh > 0 ? be << (sh & 31) : be >> ((-sh) & 31);
                 B.in[lds_at[k]] = v & mask[k];
             }
         }
@@ -616,6 +778,7 @@ __device__ __forceinline__ void qam_rows_to_punctured(const QamTxParams &Q, cons
     __syncthreads();
     // ---- rawofdm/src/lib/qam/raw_conv.cc:46-51, 32 input bits -> 64 coded bits per thread:
     // polynomial 121 taps u[n], u[n-3..n-6]; 91 taps u[n], u[n-1], u[n-3], u[n-4], u[n-6]
+    SEC("q_enc");
     for (RowWalk w = wk.enc; w.r < rows_here; w.next()) {
         const uint32_t off = B.row[4u * w.r + 3] + 32u * w.x, q = off >> 5, sh = off & 31u;
         const uint32_t *W = B.in + w.r * B.in_stride;
@@ -762,33 +925,137 @@ __global__ void __launch_bounds__(256) k_raw_qam_tx_fast(QamTxParams Q, const ui
     }
 }
 
+// t / d and t % d for small t (below 2^22) without an integer division: the quotient estimate from
+// a float reciprocal is off by at most one, downwards, which one comparison repairs.
+struct SmallDiv {
+    uint32_t d;
+    float inv;
+    __device__ __forceinline__ explicit SmallDiv(uint32_t dd) : d(dd), inv(1.0f / (float)dd) {}
+    __device__ __forceinline__ void divmod(uint32_t t, uint32_t &q, uint32_t &r) const
+    {
+        q = (uint32_t)((float)t * inv);
+        r = t - q * d;
+        if ((int32_t)r < 0) { q--; r += d; }
+        if (r >= d) { q++; r -= d; }
+    }
+};
+
+// ---- pieces shared by the fused bytes -> IQ kernels --------------------------------------------
+// Index bytes of a pass: one row of IDX_PAD extra bytes behind the ncarriers level-index bytes of
+// every symbol; the extra bytes hold the LUT slots of the three values a bin can have without
+// carrying data (zero, pilot +1, pilot -1), so that the modulator fetches EVERY bin the same way:
+// one byte from the row, one complex value from the LUT -- no per-bin case distinction.
+constexpr uint32_t IDX_PAD = 16;          // keeps rows 16-byte aligned
+constexpr uint32_t LUT_ZERO = 64, LUT_PLUS = 65, LUT_MINUS = 66, FUSED_LUT = 72;
+
+// complex value of every index byte (I index << 3 | Q index) plus the three fixed slots
+template <int QB>
+__device__ __forceinline__ void fused_lut_fill(v2f *s_lut, float scale, int tid, int nthr)
+{
+    constexpr uint32_t QS = QB / 2 > 1 ? QB / 2 : 1;
+    for (int i = tid; i < (int)FUSED_LUT; i += nthr) {
+        v2f v = {0.f, 0.f};
+        if (i < 64) {
+            const uint32_t hi = (uint32_t)i >> 3, lo = (uint32_t)i & 7u;
+            if (hi < (1u << QS) && lo < (1u << QS)) v = (v2f){qam_level(hi, QS, scale), QB == 1 ? 0.f : qam_level(lo, QS, scale)};
+        } else if (i == (int)LUT_PLUS) {
+            v.x = 1.f;
+        } else if (i == (int)LUT_MINUS) {
+            v.x = -1.f;
+        }
+        s_lut[i] = v;
+    }
+}
+
+// byte offset, inside a symbol's index row, of the byte that selects the value of bin code `code`
+// (s_src: >= 0 data carrier, -1 zero, -2 pilot +1, -3 pilot -1)
+template <int QB, int NC, int NP>
+__device__ __forceinline__ uint32_t fused_idx_offset(int code, uint32_t ncarriers)
+{
+    return code >= 0 ? GroupLut<QB, NC, NP>::offset_of((uint32_t)code, ncarriers / 16u) : ncarriers + (uint32_t)(-1 - code);
+}
+
+// the three fixed slots behind a row's index bytes
+__device__ __forceinline__ void fused_idx_fixed(uint8_t *row_pad)
+{
+    row_pad[0] = (uint8_t)LUT_ZERO;
+    row_pad[1] = (uint8_t)LUT_PLUS;
+    row_pad[2] = (uint8_t)LUT_MINUS;
+}
+
 // ---- bytes -> IQ in one kernel: the bit chain above feeding the modulator, the carrier values never
-// leave the CU.  A workgroup takes RAW_WAVES * SPW rows (OFDM symbols) per pass: all threads run
-// the bit chain into one level-index byte per carrier (its staging areas lie in the modulator's
-// still unused transposition areas), then every wave modulates its SPW symbols, taking the data
-// values from the index bytes and the level table instead of from memory, and copies the preamble
-// rows of the frames that start in its symbols.  Needs whole frames of Q.nsymbols symbols
-// (R.frame_size), R.data_tones == Q.ncarriers, a multiple of 16.
+// leave the CU.  Two forms with the same LDS layout per wavefront -- SPW symbol areas; the wave's SPW
+// index rows sit at the END of its areas (read into registers before the transform overwrites
+// them), the bit chain's staging at the START of the areas:
+//   k_raw_tx    workgroup form: the W waves run the bit chain of W * SPW symbols together (phases
+//               separated by workgroup barriers, staging across the areas of the leading waves),
+//               then every wave modulates its SPW symbols;
+//   k_raw_tx_w  wave form: every wave runs the bit chain of its own SPW symbols inside its own areas
+//               and modulates them, handing over inside the wave only -- no wave waits for another.
+// Either way a wave copies the preamble rows of the frames that start in its symbols.  Needs whole
+// frames of Q.nsymbols symbols (R.frame_size), R.data_tones == Q.ncarriers, a multiple of 16.
+template <int L, int M, int QB>
+__device__ __forceinline__ void fused_modulate_round(const RawParams &R, const uint8_t *irow, const uint32_t (&ioff)[M],
+                                                     bool active, int slot, int t, int lane, v2f *T, const v2f *T_wave,
+                                                     const v2f *s_tw, const v2f *s_lut, uint32_t first_frame,
+                                                     uint32_t first_in_frame, uint32_t syms_here, const SmallDiv &fdiv,
+                                                     float2 *__restrict__ iq)
+{
+    constexpr int S = L > M ? L : M, SPW = 64 / S;
+    const uint32_t row_len = R.n + R.cp;
+    SEC("m_gather");
+    // the round's first symbol is symbol first_in_frame of frame first_frame; this lane's is `slot` further on
+    uint32_t row = ROW_DROPPED;
+    if (active) {
+        uint32_t df, sf;
+        fdiv.divmod(first_in_frame + (uint32_t)slot, df, sf);
+        row = (first_frame + df) * (R.frame_size + R.n_pre) + R.n_pre + sf;
+    }
+    // (every lane reads -- cheaper than masking the reads: lanes beyond L fetch the zero slot, slots
+    //  beyond the pass's last symbol are given a row of the pass by the caller)
+    v2f x[M];
+#pragma unroll
+    for (int m = 0; m < M; m++) x[bit_reverse(m, M)] = s_lut[irow[ioff[m]]];
+    wave_sync();                                              // index bytes read: the areas may be overwritten
+    raw_transform_store<L, M>(active, t, lane, row, x, T, T_wave, s_tw, R.n, R.cp, iq);
+    SEC("m_pre");
+    // ---- preamble rows of the frames that start in this wave's symbols
+    // (gr-digital ofdm_insert_preamble as wired at rawofdm/src/python/raw_ofdm_mod.py:45,50-52)
+#pragma unroll
+    for (int sl = 0; sl < SPW; sl++) {
+        uint32_t df, sf;
+        fdiv.divmod(first_in_frame + (uint32_t)sl, df, sf);
+        if ((uint32_t)sl >= syms_here || sf != 0u) continue;
+        const size_t frow = (size_t)(first_frame + df) * (R.frame_size + R.n_pre);
+        const uint32_t cnt = R.n_pre * row_len;
+        if ((row_len & 1u) == 0u) {
+            const float4 *src4 = reinterpret_cast<const float4 *>(R.pre_rows);
+            const __amdgpu_buffer_rsrc_t win = iq_window(iq + frow * row_len);
+            for (uint32_t i = lane; i < cnt / 2; i += 64) iq_store<RAW_ROW_AUX>(win, i, src4[i]);
+        } else {
+            float2 *dst = iq + frow * row_len;
+            for (uint32_t i = lane; i < cnt; i += 64) dst[i] = R.pre_rows[i];
+        }
+    }
+}
+
+// groups of 16 carriers one lane works on per pass (the raw input of the NEXT pass waits in registers)
+constexpr int FUSED_IT = 3;
+
 template <int L, int M, int W, int QB, int NC, int NP>
 __global__ void __launch_bounds__(64 * W)
-k_raw_tx(RawParams R, QamTxParams Q, const uint8_t *__restrict__ data, float2 *__restrict__ iq, uint32_t in_stride,
-         uint32_t cod_stride, uint32_t pun_stride, uint32_t rows_pass)
+k_raw_tx(RawParams R, QamTxParams Q, const uint8_t *__restrict__ data, float2 *__restrict__ iq, uint32_t rounds,
+         uint32_t wave_bytes)
 {
-    constexpr int N = L * M, S = L > M ? L : M, SPW = 64 / S, ROWS = W * SPW;
-    constexpr int TT = M * (L + 1);
-    constexpr uint32_t QS = QB / 2 > 1 ? QB / 2 : 1;
-    const int TS = ((TT > (int)(R.n + R.cp) ? TT : (int)(R.n + R.cp)) + 1) & ~1;
+    constexpr int N = L * M, S = L > M ? L : M, SPW = 64 / S, TS = raw_area<L, M>();
+    using Units = UnitBits<QB, NC, NP>;
+    using GLut = GroupLut<QB, NC, NP>;
     extern __shared__ __align__(16) unsigned char s_raw[];
     v2f *s_tw = reinterpret_cast<v2f *>(s_raw);                            // N
-    v2f *s_t = s_tw + N;                                                   // ROWS * TS
-    uint32_t *s_row = reinterpret_cast<uint32_t *>(s_t + ROWS * TS);       // 4 * rows_pass
-    int16_t *s_src = reinterpret_cast<int16_t *>(s_row + 4 * rows_pass);   // N
-    uint8_t *s_idx = reinterpret_cast<uint8_t *>(s_src + N);               // rows_pass * ncarriers
-    __shared__ float s_lv[8];
-    // the bit chain's staging lives where the transposition areas will be
-    uint32_t *s_in = reinterpret_cast<uint32_t *>(s_t);
-    uint32_t *s_cod = s_in + in_stride * rows_pass;
-    uint32_t *s_pun = s_cod + cod_stride * rows_pass;             // s_cod / s_pun: the encoder's streams A / B
+    int16_t *s_src = reinterpret_cast<int16_t *>(s_tw + N);                // N
+    __shared__ v2f s_lut[FUSED_LUT];
+    __shared__ uint32_t s_glut[GLut::WORDS];
+    const uint32_t idx_stride = Q.ncarriers + IDX_PAD;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < N; i += 64 * W) {
@@ -796,68 +1063,83 @@ k_raw_tx(RawParams R, QamTxParams Q, const uint8_t *__restrict__ data, float2 *_
         s_tw[i] = (v2f){w.x, w.y};
         s_src[i] = R.src[i];
     }
-    if (tid < (1 << QS)) s_lv[tid] = qam_level((uint32_t)tid, QS, Q.scale);
+    fused_lut_fill<QB>(s_lut, Q.scale, tid, 64 * W);
+    GLut::fill(s_glut, tid, 64 * W);
+    __syncthreads();                                              // the only workgroup barrier
+
+    // this wave's LDS: SPW symbol areas, then (rounds > 1) the index rows of a pass; with one round
+    // per pass the SPW index rows lie at the end of the areas instead (they are in registers before
+    // the transform overwrites them)
+    v2f *T_wave = reinterpret_cast<v2f *>(s_raw + (size_t)N * (sizeof(float2) + sizeof(int16_t)) + (size_t)wave * wave_bytes);
+    uint8_t *idx_wave = rounds > 1u ? reinterpret_cast<uint8_t *>(T_wave + SPW * TS)
+                                    : reinterpret_cast<uint8_t *>(T_wave + SPW * TS) - SPW * idx_stride;
+    const uint32_t rows_wave = rounds * SPW;                      // symbols per pass of this wave
+    const uint32_t G = Q.ncarriers / 16u;
+    const uint32_t sym_bytes = G * Units::IN_BYTES;               // input bytes behind one symbol
+    const int t = lane % S, slot = lane / S;
+    v2f *T = T_wave + slot * TS;
+    // where the index byte of each of the lane's M bins sits in a symbol's row: the same for every symbol
+    uint32_t ioff[M];
+#pragma unroll
+    for (int m = 0; m < M; m++) ioff[m] = fused_idx_offset<QB, NC, NP>(t < L ? s_src[t + L * m] : -1, Q.ncarriers);
+    // the lane's groups of a pass: (row, c') of item lane + 64 it -- the same in every pass
+    const SmallDiv gdiv(G), fdiv(R.frame_size);                   // (R.frame_size == Q.nsymbols)
+    uint32_t g_row[FUSED_IT], g_c[FUSED_IT];
+#pragma unroll
+    for (int it = 0; it < FUSED_IT; it++) gdiv.divmod((uint32_t)lane + 64u * it, g_row[it], g_c[it]);
 
     const uint32_t n_rows = R.n_sym;
-    const uint32_t cod_per_row = Q.cbps / NP * NC, in_per_row = cod_per_row >> 1;
-    const uint32_t words_per_row = (cod_per_row + 63u) / 64u;
-    constexpr uint32_t PIN = NC == 4 ? 4 : 3;
-    const uint32_t units = (cod_per_row + 32u * PIN - 1u) / (32u * PIN);
-    const uint32_t G = Q.ncarriers / 16u;
-    const QamWalks walks = {RowWalk(tid, 64 * W, in_stride), RowWalk(tid, 64 * W, words_per_row),
-                            RowWalk(tid, 64 * W, units)};
-    const RowWalk walk_car(tid, 64 * W, G);
-    const QamBufs bufs = {s_in, s_cod, s_pun, s_row, in_stride, cod_stride, pun_stride};
-    const int t = lane % S, slot = lane / S;
-    v2f *T = s_t + (wave * SPW + slot) * TS;
-    const uint32_t row_len = R.n + R.cp;
-
-    for (uint32_t row0 = blockIdx.x * rows_pass; row0 < n_rows; row0 += gridDim.x * rows_pass) {
-        const uint32_t rows_here = n_rows - row0 < rows_pass ? n_rows - row0 : rows_pass;
-        // ---- bit chain (its first barrier also closes the previous pass)
-        qam_rows_to_punctured<NC, NP, true>(Q, data, row0, rows_here, bufs, walks, in_per_row);
-        for (RowWalk w = walk_car; w.r < rows_here; w.next())
-            qam_group_to_idx<QB, NC, NP>(s_cod + w.r * cod_stride, s_pun + w.r * pun_stride, w.x, G,
-                                         s_idx + w.r * Q.ncarriers);
-        __syncthreads();                                          // index bytes complete, staging dead
-
-        // ---- modulator, SPW symbols per wave and round (the waves run their rounds independently)
-        for (uint32_t sub = 0; sub < rows_here; sub += (uint32_t)ROWS) {
-        const uint32_t r_in = sub + (uint32_t)(wave * SPW + slot), sym = row0 + r_in;
-        const bool active = r_in < rows_here;
-        uint32_t row = ROW_DROPPED;
-        if (active) row = (sym / R.frame_size) * (R.frame_size + R.n_pre) + R.n_pre + sym % R.frame_size;
-        v2f x[M];
-        if (active && t < L) {
-            const uint8_t *irow = s_idx + r_in * Q.ncarriers;
+    const uint32_t n_items = (n_rows + rows_wave - 1u) / rows_wave;
+    const uint32_t step = gridDim.x * W;
+    typename Units::Raw raw[FUSED_IT];
+    // fetch of the pass that starts at symbol row0 (nothing is waited for here)
+    auto fetch_pass = [&](uint32_t row0) {
+        const uint32_t rows_here = n_rows - row0 < rows_wave ? n_rows - row0 : rows_wave;
+        const uint32_t f0 = row0 / R.frame_size, s0 = row0 - f0 * R.frame_size;      // wave-uniform
 #pragma unroll
-            for (int m = 0; m < M; m++) {
-                const int code = s_src[t + L * m];
-                const uint32_t ib = irow[code >= 0 ? code : 0];
-                v2f v = {s_lv[ib >> 3], QB == 1 ? 0.f : s_lv[ib & 7u]};
-                if (code < 0) v = (v2f){code == -2 ? 1.f : (code == -3 ? -1.f : 0.f), 0.f};
-                x[bit_reverse(m, M)] = v;
+        for (int it = 0; it < FUSED_IT; it++) {
+            if (g_row[it] < rows_here) {
+                uint32_t f, sf;
+                fdiv.divmod(s0 + g_row[it], f, sf);
+                const uint8_t *p = data + (size_t)(f0 + f) * Q.frame_bytes + sf * sym_bytes + g_c[it] * (uint32_t)Units::IN_BYTES;
+                Units::fetch(raw[it], p, (sf | g_c[it]) != 0u, !(sf == Q.nsymbols - 1u && g_c[it] == G - 1u));
             }
         }
-        raw_transform_store<L, M>(active, t, lane, row, x, T, s_t + wave * SPW * TS, TS, s_tw, R.n, R.cp, iq);
-        // ---- preamble rows of the frames that start in this wave's symbols
-        // (gr-digital ofdm_insert_preamble as wired at rawofdm/src/python/raw_ofdm_mod.py:45,50-52)
+    };
+    uint32_t item = blockIdx.x * W + wave;
+    if (item < n_items) fetch_pass(item * rows_wave);
+    for (; item < n_items; item += step) {
+        const uint32_t row0 = item * rows_wave;
+        const uint32_t rows_here = n_rows - row0 < rows_wave ? n_rows - row0 : rows_wave;
+        const uint32_t f0 = row0 / R.frame_size, s0 = row0 - f0 * R.frame_size;
+        wave_sync();                                              // the previous pass is done with the areas
+        // ---- bit chain, one lane per group of 16 carriers (carriers c', c' + G, .. c' + 15 G of a symbol)
+        SEC("q_idx");
 #pragma unroll
-        for (int sl = 0; sl < SPW; sl++) {
-            const uint32_t r_s = sub + (uint32_t)(wave * SPW + sl), sym_s = row0 + r_s;
-            if (r_s >= rows_here || sym_s % R.frame_size != 0u) continue;
-            const size_t frow = (size_t)(sym_s / R.frame_size) * (R.frame_size + R.n_pre);
-            const uint32_t cnt = R.n_pre * row_len;
-            if ((row_len & 1u) == 0u) {
-                const float4 *src4 = reinterpret_cast<const float4 *>(R.pre_rows);
-                const __amdgpu_buffer_rsrc_t win = iq_window(iq + frow * row_len);
-                for (uint32_t i = lane; i < cnt / 2; i += 64) iq_store<RAW_ROW_AUX>(win, i, src4[i]);
-            } else {
-                float2 *dst = iq + frow * row_len;
-                for (uint32_t i = lane; i < cnt; i += 64) dst[i] = R.pre_rows[i];
+        for (int it = 0; it < FUSED_IT; it++) {
+            if (g_row[it] < rows_here) {
+                Units ub;
+                ub.encode(raw[it]);
+                uint8_t *irow = idx_wave + g_row[it] * idx_stride;
+                if constexpr (GLut::USED) {
+                    uint32_t out[4];
+                    GLut::emit(ub, s_glut, out);
+                    *reinterpret_cast<uint4 *>(irow + 16u * g_c[it]) = make_uint4(out[0], out[1], out[2], out[3]);
+                } else {
+                    emit_unit_group<QB, NC, NP, (QB / 2 > 1 ? QB / 2 : 1)>(ub, irow + g_c[it], G, std::make_integer_sequence<int, 16>{});
+                }
+                if (g_c[it] == 0) fused_idx_fixed(irow + Q.ncarriers);
             }
         }
-        wave_sync();                                          // the areas are rewritten in the next round
+        wave_sync();                                              // index bytes complete
+        // the next pass's input is on its way while this one is modulated
+        if (item + step < n_items) fetch_pass((item + step) * rows_wave);
+        // ---- modulator, SPW symbols per round
+        for (uint32_t sub = 0; sub < rows_here; sub += (uint32_t)SPW) {
+            const uint32_t r_in = sub + (uint32_t)slot;
+            fused_modulate_round<L, M, QB>(R, idx_wave + (r_in < rows_here ? r_in : sub) * idx_stride, ioff, r_in < rows_here, slot, t, lane, T, T_wave,
+                                           s_tw, s_lut, f0, s0 + sub, rows_here - sub, fdiv, iq);
+            wave_sync();                                          // the areas are rewritten in the next round
         }
     }
 }
@@ -982,50 +1264,45 @@ void raw_finish_sizes(ofdmtx_raw_plan *pl, uint64_t n_sym, uint64_t n_frames, ui
 
 }  // namespace
 
-// launch of the fused bytes -> IQ kernel for one FFT size; W waves per workgroup
+// launch of the fused bytes -> IQ kernel for one FFT size; W waves per workgroup, `rounds` rounds of
+// 64 / max(L, M) symbols per wave and pass
 template <int L, int M, int W>
 static int launch_raw_tx(const ofdmtx_ctx *ctx, const RawParams &rp, const QamTxParams &Q, int key, const uint8_t *d_bytes,
-                         float2 *iq, hipStream_t st)
+                         float2 *iq, uint32_t rounds, hipStream_t st)
 {
-    constexpr int N = L * M, S = L > M ? L : M, SPW = 64 / S, ROWS = W * SPW, TT = M * (L + 1);
-    const int TS = ((TT > (int)(rp.n + rp.cp) ? TT : (int)(rp.n + rp.cp)) + 1) & ~1;
-    const uint32_t cod_bits = Q.cbps / Q.np * Q.nc;
-    // the two encoder streams, one word per 32 input bits each, plus the word a 12-bit window may reach into
-    const uint32_t cod_stride = (cod_bits + 63u) / 64u + 1u, pun_stride = cod_stride;
-    const uint32_t in_stride = (cod_bits / 2u + 31u) / 32u + 4u;
-    // rows per pass of the bit chain: rounds of ROWS rows, about 4096 carrier values, and its staging
-    // must fit into the transposition areas it borrows
-    const size_t stage_row = (size_t)(in_stride + cod_stride + pun_stride) * sizeof(uint32_t);
-    const size_t areas = (size_t)ROWS * TS * sizeof(float2);
-    if (stage_row * ROWS > areas) return OFDMTX_ESHAPE;
-    uint32_t rounds = (4096u / Q.ncarriers + ROWS - 1) / ROWS;
-    if (rounds < 1) rounds = 1;
-    while (rounds > 1 && (stage_row * ROWS * rounds > areas || (size_t)ROWS * rounds * Q.ncarriers > 16384u)) rounds--;
-    const uint32_t rows_pass = ROWS * rounds;
-    const size_t lds = (size_t)N * sizeof(float2) + areas + 16u * rows_pass + (size_t)N * sizeof(int16_t) +
-                       (size_t)rows_pass * Q.ncarriers + 16u;
-    if (lds > 160u * 1024u - 64u) return OFDMTX_ESHAPE;
-    uint64_t blocks = ((uint64_t)rp.n_sym + rows_pass - 1) / rows_pass;
-    const uint64_t per_cu = 160u * 1024u / lds ? 160u * 1024u / lds : 1;
-    const uint64_t cap = (uint64_t)ctx->n_cu * (per_cu < 8 ? per_cu : 8);
-    if (blocks > cap) blocks = cap;
+    constexpr int N = L * M, S = L > M ? L : M, SPW = 64 / S, TS = raw_area<L, M>();
+    const size_t wave_area = (size_t)SPW * TS * sizeof(float2), idx_row = Q.ncarriers + IDX_PAD;
+    // as many rounds per pass as FUSED_IT groups per lane cover (64 FUSED_IT groups of 16 carriers per wave)
+    const uint32_t G = Q.ncarriers / 16u, max_rounds = 64u * FUSED_IT / (SPW * G);
+    if (max_rounds < 1u) return OFDMTX_ESHAPE;
+    if (rounds < 1u || rounds > max_rounds) rounds = max_rounds;
+    if (rounds == 1u && SPW * idx_row >= wave_area) return OFDMTX_ESHAPE;   // no room to alias the index rows
+    const size_t wave_bytes = wave_area + (rounds > 1u ? (size_t)rounds * SPW * idx_row : 0u);
+    const size_t lds = (size_t)N * (sizeof(float2) + sizeof(int16_t)) + (size_t)W * wave_bytes;
+    if (lds > 160u * 1024u - 1024u) return OFDMTX_ESHAPE;
+    const uint64_t n_items = ((uint64_t)rp.n_sym + rounds * SPW - 1) / (rounds * SPW);
+    uint64_t blocks = (n_items + W - 1) / W;
+    hipFuncAttributes fa;
 #define LAUNCH_RTX(QB_, NC_, NP_)                                                                          \
     do {                                                                                                   \
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_raw_tx<L, M, W, QB_, NC_, NP_>),      \
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
+        const void *fn = reinterpret_cast<const void *>(&k_raw_tx<L, M, W, QB_, NC_, NP_>);                \
+        HIPCHK(hipFuncGetAttributes(&fa, fn));                                                             \
+        const uint64_t per_cu = 160u * 1024u / (lds + fa.sharedSizeBytes) ? 160u * 1024u / (lds + fa.sharedSizeBytes) : 1; \
+        const uint64_t cap = (uint64_t)ctx->n_cu * (per_cu < 8 ? per_cu : 8);                              \
+        if (blocks > cap) blocks = cap;                                                                    \
+        HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));             \
         hipLaunchKernelGGL((k_raw_tx<L, M, W, QB_, NC_, NP_>), dim3((unsigned)blocks), dim3(64 * W), lds,  \
-                           st, rp, Q, d_bytes, iq, in_stride, cod_stride, pun_stride, rows_pass);          \
+                           st, rp, Q, d_bytes, iq, rounds, (uint32_t)wave_bytes);                          \
     } while (0)
     switch (key) {
     case 144: LAUNCH_RTX(1, 4, 4); break;
-    case 164: LAUNCH_RTX(1, 6, 4); break;
     case 244: LAUNCH_RTX(2, 4, 4); break;
     case 264: LAUNCH_RTX(2, 6, 4); break;
     case 444: LAUNCH_RTX(4, 4, 4); break;
     case 464: LAUNCH_RTX(4, 6, 4); break;
     case 643: LAUNCH_RTX(6, 4, 3); break;
     case 664: LAUNCH_RTX(6, 6, 4); break;
-    default: return OFDMTX_ESHAPE;
+    default: return OFDMTX_ESHAPE;      // (1, (6, 4)): a group's input is a byte and a half
     }
 #undef LAUNCH_RTX
     HIPCHK(hipGetLastError());
@@ -1211,7 +1488,7 @@ int ofdmtx_raw_qam_tx(ofdmtx_ctx *ctx, int qambits, int nc, int np, uint32_t nca
     const uint32_t rows_fit = tail_fixed < 40000u ? (uint32_t)((48000u - tail_fixed) / row_bytes) : 0u;
     if (rows_fast > rows_fit) rows_fast = rows_fit;
     const size_t lds_fast = row_bytes * rows_fast + tail_fixed + 16u;
-    const bool fast_ok = rows_fast >= 1u && Q.total_bytes >= 4u && (Q.cbps / s) * sizeof(uint16_t) < 40000u && Q.cbps / 16u < 4096u;
+    const bool fast_ok = rows_fast >= 1u && Q.total_bytes >= 4u && Q.total_bytes < 0x7FFFFFF0ull && (Q.cbps / s) * sizeof(uint16_t) < 40000u && Q.cbps / 16u < 4096u;
     const uint64_t iters_fast = fast_ok ? (n_rows + rows_fast - 1) / rows_fast : 1;
     const unsigned grid_fast = (unsigned)(iters_fast < cap ? iters_fast : cap);
 #define LAUNCH_QAM(QB_, NC_, NP_)                                                                         \
@@ -1261,20 +1538,22 @@ int ofdmtx_raw_tx(ofdmtx_ctx *ctx, const ofdmtx_raw_plan *pl, int qambits, int n
     QamTxParams Q;
     int rc = qam_params(qambits, nc, np, rp.data_tones, rp.frame_size, rp.n_sym / rp.frame_size, &Q);
     if (rc) return rc;
-    if (Q.total_bytes < 4u || Q.cbps / 16u >= 4096u) return OFDMTX_ESHAPE;
+    if (Q.total_bytes < 4u || Q.total_bytes >= 0x7FFFFFF0ull || Q.cbps / 16u >= 4096u) return OFDMTX_ESHAPE;
     HIPCHK(hipSetDevice(ctx->device));
     const int key = qambits * 100 + nc * 10 + np;
     float2 *iq = reinterpret_cast<float2 *>(d_iq);
     hipStream_t st = (hipStream_t)stream;
+    // Waves per workgroup as measured per size (64-QAM r3/4, 1.05e6 / 2.6e5 symbols, one box, ms):
+    //   N = 64: 4 -> 0.183 (2: 0.185, 8: 0.181, 12: 0.219)     N = 128: 4 -> 0.372 (2: 0.380, 8: 0.378, 12: 0.429)
+    //   N = 256: 12 -> 0.684 (4: 0.715, 8: 0.770, 2: 0.845)    N = 512: 8 -> 0.484 (4: 0.558, 12: 0.559)
+    //   N = 1024: 6 -> 1.065 (2: 1.075, 4: 1.206; the two kernels: 1.34)
+    // Every wave takes as many rounds per pass as FUSED_IT groups per lane cover.
     switch (rp.n) {
-    // waves per workgroup as measured: two for the short symbols (0.34 against 0.39 ms at N=64, 0.61
-    // against 0.72 ms at N=128, 64-QAM, 1.05e6 symbols; one and eight are slower), four for the long ones
-    case 64: return launch_raw_tx<8, 8, 2>(ctx, rp, Q, key, d_bytes, iq, st);
-    case 128: return launch_raw_tx<8, 16, 2>(ctx, rp, Q, key, d_bytes, iq, st);
-    case 256: return launch_raw_tx<16, 16, 4>(ctx, rp, Q, key, d_bytes, iq, st);
-    case 512: return launch_raw_tx<16, 32, 4>(ctx, rp, Q, key, d_bytes, iq, st);
-    // N = 1024: the 10 KB areas per symbol leave 4 waves per CU, too few for the bit chain's phases;
-    // the two kernels are faster there (1.5 against 2.0 ms per 2.6e5 symbols)
+    case 64: return launch_raw_tx<8, 8, 4>(ctx, rp, Q, key, d_bytes, iq, 0, st);
+    case 128: return launch_raw_tx<8, 16, 4>(ctx, rp, Q, key, d_bytes, iq, 0, st);
+    case 256: return launch_raw_tx<16, 16, 12>(ctx, rp, Q, key, d_bytes, iq, 0, st);
+    case 512: return launch_raw_tx<16, 32, 8>(ctx, rp, Q, key, d_bytes, iq, 0, st);
+    case 1024: return launch_raw_tx<32, 32, 6>(ctx, rp, Q, key, d_bytes, iq, 0, st);
     default: return OFDMTX_ESHAPE;
     }
 }

@@ -392,8 +392,9 @@ def test_gpu_bytes_to_iq_and_back(txctx, bitrate, nfft):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nfft,cp", [(64, 16), (128, 32), (256, 64), (256, 7), (512, 64), (1024, 256), (1024, 16)])
-def test_gpu_bytes_to_iq_in_one_kernel(txctx, nfft, cp):
+@pytest.mark.parametrize("nfft,cp,frame", [(64, 16, 16), (64, 16, 4), (128, 32, 16), (256, 64, 16), (256, 7, 16), (256, 64, 5),
+                                           (256, 64, 1), (512, 64, 16), (1024, 256, 4), (1024, 16, 4)])
+def test_gpu_bytes_to_iq_in_one_kernel(txctx, nfft, cp, frame):
     """ofdm_mod.modulate_bytes (one kernel: bit chain + modulator) gives exactly the samples of
     qam_tx followed by modulate_frames, at every rate; frames enough for several passes."""
     import torch
@@ -404,13 +405,15 @@ def test_gpu_bytes_to_iq_in_one_kernel(txctx, nfft, cp):
     assert p.data_tones % 16 == 0
     rng = np.random.default_rng(nfft + cp)
     for bitrate in range(1, 9):
-        nsymbols = 16 if nfft < 1024 else 4
-        n_frames = 700 if nfft <= 128 else 150
+        nsymbols = frame                 # (frames shorter than a wave's pass: several frames start inside one pass)
+        n_frames = (700 if nfft <= 128 else 150) * 16 // frame + 1
         tx = raw.qam_tx(bitrate, p.data_tones, nsymbols, ctx=txctx)
         data = torch.from_numpy(rng.integers(0, 256, n_frames * tx.framebytes, dtype=np.uint8)).to(txctx.device)
         mod.fused = False
         got = mod.modulate_bytes(bitrate, data, nsymbols)
-        assert mod.fused == (nfft <= 512), "one kernel up to N = 512, the two kernels above"
+        # one kernel at every size; the rate (1, (6, 4)) -- "DONT USE" in raw_qam.py:21 -- gives a group of 16
+        # carriers a byte and a half of input and is left to the two kernels
+        assert mod.fused == (bitrate != 2), (bitrate, nfft)
         want = mod.modulate_frames(tx.modulate(data), nsymbols)
         assert torch.equal(got.view(torch.float32), want.view(torch.float32)), (bitrate, nfft)
 
