@@ -452,6 +452,63 @@ def test_gpu_qam_tx_rejects_bad_geometry(txctx):
         tx.modulate(b"\x00" * tx.framebytes)
 
 
+# ------------------------------------------------------------------------------ known answers derived by hand
+
+def test_qam_gray_levels_by_hand():
+    """The recursion of rawofdm/src/lib/qam/raw_qam.cc:63-74 (pt = bit * flip + 2 pt; flip *= -bit, with
+    bit in {-1, +1}, first bit first) worked out on paper for every bit pattern:
+      1 bit : 0 -> -1, 1 -> +1
+      2 bits: 00 -> -3 (pt -1, flip +1; then -1 - 2), 01 -> -1, 11 -> +1, 10 -> +3  (Gray along the axis)
+      3 bits: 000 -> -7, 001 -> -5, 011 -> -3, 010 -> -1, 110 -> +1, 111 -> +3, 101 -> +5, 100 -> +7
+    and the scale of :39-54 with the powers of :120-147: BPSK sqrt(1), QPSK sqrt(1/2) per axis,
+    16-QAM sqrt(0.5 * 2 / 10), 64-QAM sqrt(0.5 * 4 / 84).  An oracle that misread the recursion or the
+    bit order fails here, whatever the GPU does."""
+    by_hand = {1: {"0": -1, "1": 1},
+               2: {"00": -3, "01": -1, "11": 1, "10": 3},
+               3: {"000": -7, "001": -5, "011": -3, "010": -1, "110": 1, "111": 3, "101": 5, "100": 7}}
+    for numbits, table in by_hand.items():
+        for bits, level in table.items():
+            got = ro.qam_axis([int(c) for c in bits], numbits, np.float32(1.0))
+            assert got.tolist() == [float(level)], (bits, got)
+    for nbits, scale2 in ((1, 1.0), (2, 0.5), (4, 0.5 * 2 / 10), (6, 0.5 * 4 / 84)):
+        numbits, power = ro._QAM[nbits]
+        assert abs(float(ro.qam_scale(numbits, power)) - np.sqrt(scale2)) < 1e-7
+    # one whole 64-QAM value: items 1,0,0 | 0,1,1 -> (+7, -3) * sqrt(1/42)
+    v = ro.qam_enc([1, 0, 0, 0, 1, 1], 6)
+    assert np.allclose(v, (7 - 3j) * np.sqrt(1 / 42.0), rtol=1e-6)
+    # unit mean power over the whole constellation (what the scale is for)
+    allv = ro.qam_enc(np.array([[(i >> (5 - b)) & 1 for b in range(6)] for i in range(64)]).reshape(-1), 6)
+    assert abs(np.mean(np.abs(allv) ** 2) - 1.0) < 1e-6
+
+
+def test_bit_interleaver_map_by_hand():
+    """rawofdm/src/lib/qam/raw_intrlv.cc:22-30 evaluated by hand for 8 carriers of 4 bits (cbps 32, s 2):
+    i = 2 (k mod 16) + k div 16, then j = 2 (i div 2) + (i + 32 - i div 2) mod 2, i.e. the pairs (4m, 4m+1) stay
+    and the pairs (4m+2, 4m+3) swap; and for 16 carriers of 2 bits (s 1: the first step only)."""
+    want = [0, 3, 4, 7, 8, 11, 12, 15, 16, 19, 20, 23, 24, 27, 28, 31,
+            1, 2, 5, 6, 9, 10, 13, 14, 17, 18, 21, 22, 25, 26, 29, 30]
+    assert ro.intrlv_bit_map(8, 4).tolist() == want
+    assert ro.intrlv_bit_map(16, 2).tolist() == list(range(0, 32, 2)) + list(range(1, 32, 2))
+    assert ro.intrlv_bit_map(16, 1).tolist() == list(range(16))
+    # the block scatters: out[map[j]] = in[j] (raw_intrlv.cc:69-73)
+    items = np.arange(32) % 7
+    out = ro.intrlv_bit(items, 8, 4, False)
+    assert all(out[want[j]] == items[j] for j in range(32))
+
+
+def test_encoder_taps_by_hand():
+    """rawofdm/src/lib/qam/raw_conv.cc:46-51 with POLYS {121, 91} (spiral/defs.h:3-7): a single 1 bit
+    followed by zeros reads the polynomials out, newest bit at the register's LSB: output pair n is
+    (bit n of 121, bit n of 91) = 1111001b, 1011011b from the LSB up."""
+    items, sr = ro.conv_enc(bytes([0x80, 0x00]))
+    pairs = items.reshape(-1, 2)[:7].tolist()
+    assert pairs == [[(121 >> n) & 1, (91 >> n) & 1] for n in range(7)]
+    assert pairs == [[1, 1], [0, 1], [0, 0], [1, 1], [1, 1], [1, 0], [1, 1]]
+    assert not items[14:].any() and sr == 0x8000
+    # puncturing keeps the first np of every nc items (raw_conv.cc:150-159)
+    assert ro.conv_punc(np.arange(12) % 5, 6, 4).tolist() == [0, 1, 2, 3, 1, 2, 3, 4]
+
+
 # ------------------------------------------------------------------------------ caller surface
 
 @pytest.mark.gpu
