@@ -1,7 +1,8 @@
 // libofdmtx, variable-size OFDM modulator (the rawofdm transmit chain): carrier map -> N-point
 // inverse FFT with the DC bin in the middle of the input -> cyclic prefix -> 1/sqrt(N), with the
-// frame preambles inserted.  N = L x M is split into two in-register transforms with one LDS
-// transposition: max(L, M) lanes work on one OFDM symbol.
+// frame preambles inserted.  Up to N = 256, N = L x M is split into two in-register transforms with
+// one LDS transposition and max(L, M) lanes work on one OFDM symbol; N = 512 and 1024 take a whole
+// wave per symbol and three in-register transforms (N = A x V x V, V = N / 64 values per lane).
 //
 // Reference behaviour restated here is cited as file:line relative to the reference root.
 
@@ -86,7 +87,7 @@ __device__ __forceinline__ void dit_stage(v2f (&x)[R], std::integer_sequence<int
     (butterfly_at<R, LEN, I>(x), ...);
 }
 
-// In-register inverse DFT of R = 8, 16 or 32 points, decimation in time: x holds the input in
+// In-register inverse DFT of R = 4, 8, 16 or 32 points, decimation in time: x holds the input in
 // bit-reversed order on entry and y[p] = sum_m in[m] e^{+j 2 pi m p / R} in natural order on exit.
 template <int R>
 __device__ __forceinline__ void idft_reg(v2f (&x)[R])
@@ -94,7 +95,7 @@ __device__ __forceinline__ void idft_reg(v2f (&x)[R])
     using half_seq = std::make_integer_sequence<int, R / 2>;
     dit_stage<R, 2>(x, half_seq{});
     dit_stage<R, 4>(x, half_seq{});
-    dit_stage<R, 8>(x, half_seq{});
+    if constexpr (R >= 8) dit_stage<R, 8>(x, half_seq{});
     if constexpr (R >= 16) dit_stage<R, 16>(x, half_seq{});
     if constexpr (R >= 32) dit_stage<R, 32>(x, half_seq{});
 }
@@ -118,7 +119,12 @@ constexpr int RAW_ROW_AUX = 0;
 // float2 per symbol area: the padded transposition layout M x (L + 1), which also holds the N
 // time-domain samples afterwards (the cyclic prefix is not staged: it is read from the tail again)
 template <int L, int M>
-constexpr int raw_area() { return (M * (L + 1) + 1) & ~1; }
+constexpr int raw_area() { return L == 64 ? M * (64 + 64 / M) : (M * (L + 1) + 1) & ~1; }
+
+// Factor on the plan's twiddle table e^{j 2 pi i / N} / sqrt(N) when it is copied to LDS: the
+// three-step transform (L == 64) multiplies by two twiddles per sample, each carrying N^(-1/4).
+template <int L, int M>
+constexpr float raw_tw_factor() { return L != 64 ? 1.f : (M == 16 ? 5.656854249f : 4.756828460f); }
 
 // Steps 1b-3 of the N = L * M point modulator for the S = max(L, M) lanes of one symbol (lane t of
 // the symbol, symbol area T, wave's first area T_wave with SPW areas of raw_area<L, M>() float2 each):
@@ -137,6 +143,51 @@ __device__ __forceinline__ void raw_transform_store(bool active, int t, int lane
     constexpr int N = L * M, S = L > M ? L : M, SPW = 64 / S, TS = raw_area<L, M>();
     const uint32_t row_len = n + cp;
     SEC("t_fft1");
+    if constexpr (L == 64) {
+        // ---- one symbol per wave, V = M bins per lane, N = A x V x V with A = 64 / V:
+        //   bin k = a + A b + 64 c, sample n = V V n1 + V n2 + n3,
+        //   x[n] = sum_a W_A^{a n1} W_N^{a (V n2 + n3)} sum_b W_V^{b n2} W_N^{A b n3} sum_c W_V^{c n3} X[k]
+        // three in-register transforms of V, V and A points with an exchange through LDS after each
+        // (areas of V x (64 + A), A x (V V + pad) and N values, one after the other in the same
+        // memory); the lane is (a, b) in the first, (a, n3) in the second and (n2, n3) in the third.
+        constexpr int V = M, A = 64 / V, E1 = 64 + A, Q = V * V, E2 = Q + (V == 16 ? 16 : 8);
+        static_assert(V == 8 || V == 16, "64 lanes per symbol: N = 512 or 1024");
+        static_assert(V * E1 <= TS && A * E2 <= TS && N <= TS, "symbol area too small");
+        idft_reg<V>(x);
+        {
+            const int b = lane / A;
+#pragma unroll
+            for (int n3 = 0; n3 < V; n3++) T[n3 * E1 + lane] = cmul(x[n3], s_tw[(A * b * n3) & (N - 1)]);
+        }
+        wave_sync();
+        const int n3 = lane & (V - 1), a2 = lane / V;
+        v2f y[V];
+#pragma unroll
+        for (int b = 0; b < V; b++) y[bit_reverse(b, V)] = T[n3 * E1 + a2 + A * b];
+        wave_sync();
+        SEC("t_fft2");
+        idft_reg<V>(y);
+#pragma unroll
+        for (int n2 = 0; n2 < V; n2++) T[a2 * E2 + V * n2 + n3] = cmul(y[n2], s_tw[(a2 * (V * n2 + n3)) & (N - 1)]);
+        wave_sync();
+        SEC("t_fft3");
+#pragma unroll
+        for (int i = 0; i < Q / 64; i++) {
+            v2f z[A];
+#pragma unroll
+            for (int a = 0; a < A; a++) z[bit_reverse(a, A)] = T[a * E2 + lane + 64 * i];
+            idft_reg<A>(z);
+#pragma unroll
+            for (int n1 = 0; n1 < A; n1++) x[A * i + n1] = z[n1];
+        }
+        wave_sync();
+        SEC("t_cp");
+#pragma unroll
+        for (int i = 0; i < Q / 64; i++)
+#pragma unroll
+            for (int n1 = 0; n1 < A; n1++) T[Q * n1 + lane + 64 * i] = x[A * i + n1];
+        wave_sync();
+    } else {
     if (active && t < L) {
         idft_reg<M>(x);
 #pragma unroll
@@ -158,6 +209,7 @@ __device__ __forceinline__ void raw_transform_store(bool active, int t, int lane
         for (int q = 0; q < L; q++) T[M * q + t] = y[q];
     }
     wave_sync();
+    }
     // ---- step 3: rows to memory (a row starts on a 16-byte boundary when row_len is even; cp is
     // even then as well, so a 16-byte piece never straddles the end of the prefix)
     SEC("t_store");
@@ -193,20 +245,20 @@ __device__ __forceinline__ void raw_transform_store(bool active, int t, int lane
 // to LDS; step 2: lane p < M reads the L partial results and transforms them, and puts its
 // samples M q + p, cyclic prefix included, back into the symbol's LDS area as one output row;
 // step 3: the wave stores the rows with 16 bytes per lane, consecutive over the lanes.
-template <int L, int M>
-__global__ void __launch_bounds__(64 * RAW_WAVES)
+template <int L, int M, int W>
+__global__ void __launch_bounds__(64 * W)
 k_raw_modulate(RawParams R, const float2 *__restrict__ data, float2 *__restrict__ mapped, float2 *__restrict__ iq)
 {
     constexpr int N = L * M, S = L > M ? L : M, SPW = 64 / S, TS = raw_area<L, M>();
     extern __shared__ __align__(16) unsigned char s_raw[];
     v2f *s_tw = reinterpret_cast<v2f *>(s_raw);                            // N
-    v2f *s_t = s_tw + N;                                                   // RAW_WAVES * SPW * TS
-    int16_t *s_src = reinterpret_cast<int16_t *>(s_t + RAW_WAVES * SPW * TS);   // N
+    v2f *s_t = s_tw + N;                                                   // W * SPW * TS
+    int16_t *s_src = reinterpret_cast<int16_t *>(s_t + W * SPW * TS);   // N
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < N; i += 64 * RAW_WAVES) {
+    for (int i = tid; i < N; i += 64 * W) {
         const float2 w = R.tw[i];
-        s_tw[i] = (v2f){w.x, w.y};
+        s_tw[i] = (v2f){w.x, w.y} * raw_tw_factor<L, M>();
         s_src[i] = R.src[i];
     }
     __syncthreads();
@@ -217,7 +269,7 @@ k_raw_modulate(RawParams R, const float2 *__restrict__ data, float2 *__restrict_
     const uint32_t n_groups = (R.n_sym + SPW - 1) / SPW;
     const uint32_t n_items = n_groups + R.n_frames;
 
-    for (uint32_t item = blockIdx.x * RAW_WAVES + wave; item < n_items; item += gridDim.x * RAW_WAVES) {
+    for (uint32_t item = blockIdx.x * W + wave; item < n_items; item += gridDim.x * W) {
         if (item >= n_groups) {
             // ---- preamble rows of one frame: time-domain table -> output
             // (gr-digital ofdm_insert_preamble as wired at rawofdm/src/python/raw_ofdm_mod.py:45,50-52)
@@ -273,28 +325,28 @@ k_raw_modulate(RawParams R, const float2 *__restrict__ data, float2 *__restrict_
     }
 }
 
-template <int L, int M>
+template <int L, int M, int W>
 size_t raw_lds_bytes()
 {
     constexpr int N = L * M, S = L > M ? L : M, SPW = 64 / S, TS = raw_area<L, M>();
-    return (size_t)N * sizeof(float2) + (size_t)RAW_WAVES * SPW * TS * sizeof(float2) + (size_t)N * sizeof(int16_t);
+    return (size_t)N * sizeof(float2) + (size_t)W * SPW * TS * sizeof(float2) + (size_t)N * sizeof(int16_t);
 }
 
-template <int L, int M>
+template <int L, int M, int W = RAW_WAVES>
 int launch_raw(const ofdmtx_ctx *ctx, const RawParams &rp, const float2 *data, float2 *mapped, float2 *iq,
                hipStream_t st)
 {
     constexpr int S = L > M ? L : M, SPW = 64 / S;
-    const size_t lds = raw_lds_bytes<L, M>();
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_raw_modulate<L, M>),
+    const size_t lds = raw_lds_bytes<L, M, W>();
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_raw_modulate<L, M, W>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint64_t items = ((uint64_t)rp.n_sym + SPW - 1) / SPW + rp.n_frames;
-    uint64_t blocks = (items + RAW_WAVES - 1) / RAW_WAVES;
+    uint64_t blocks = (items + W - 1) / W;
     const uint64_t per_cu = 160u * 1024u / lds ? 160u * 1024u / lds : 1;
     const uint64_t cap = (uint64_t)ctx->n_cu * (per_cu < 8 ? per_cu : 8);
     if (blocks > cap) blocks = cap;
     if (blocks == 0) return OFDMTX_OK;
-    hipLaunchKernelGGL((k_raw_modulate<L, M>), dim3((unsigned)blocks), dim3(64 * RAW_WAVES), lds, st, rp, data,
+    hipLaunchKernelGGL((k_raw_modulate<L, M, W>), dim3((unsigned)blocks), dim3(64 * W), lds, st, rp, data,
                        mapped, iq);
     HIPCHK(hipGetLastError());
     return OFDMTX_OK;
@@ -307,8 +359,8 @@ int launch_raw_n(const ofdmtx_ctx *ctx, const RawParams &rp, const float2 *data,
     case 64: return launch_raw<8, 8>(ctx, rp, data, mapped, iq, st);
     case 128: return launch_raw<8, 16>(ctx, rp, data, mapped, iq, st);
     case 256: return launch_raw<16, 16>(ctx, rp, data, mapped, iq, st);
-    case 512: return launch_raw<16, 32>(ctx, rp, data, mapped, iq, st);
-    case 1024: return launch_raw<32, 32>(ctx, rp, data, mapped, iq, st);
+    case 512: return launch_raw<64, 8>(ctx, rp, data, mapped, iq, st);
+    case 1024: return launch_raw<64, 16>(ctx, rp, data, mapped, iq, st);
     default: return OFDMTX_ESHAPE;
     }
 }
@@ -984,16 +1036,12 @@ __device__ __forceinline__ void fused_idx_fixed(uint8_t *row_pad)
 }
 
 // ---- bytes -> IQ in one kernel: the bit chain above feeding the modulator, the carrier values never
-// leave the CU.  Two forms with the same LDS layout per wavefront -- SPW symbol areas; the wave's SPW
-// index rows sit at the END of its areas (read into registers before the transform overwrites
-// them), the bit chain's staging at the START of the areas:
-//   k_raw_tx    workgroup form: the W waves run the bit chain of W * SPW symbols together (phases
-//               separated by workgroup barriers, staging across the areas of the leading waves),
-//               then every wave modulates its SPW symbols;
-//   k_raw_tx_w  wave form: every wave runs the bit chain of its own SPW symbols inside its own areas
-//               and modulates them, handing over inside the wave only -- no wave waits for another.
-// Either way a wave copies the preamble rows of the frames that start in its symbols.  Needs whole
-// frames of Q.nsymbols symbols (R.frame_size), R.data_tones == Q.ncarriers, a multiple of 16.
+// leave the CU.  Every wave runs the bit chain of its own symbols inside its own LDS and modulates
+// them, handing over inside the wave only -- no wave waits for another.  LDS per wave: SPW symbol
+// areas, then the index rows of a pass (with one round per pass the SPW index rows sit at the END
+// of the areas instead: they are in registers before the transform overwrites them).  A wave also
+// copies the preamble rows of the frames that start in its symbols.  Needs whole frames of
+// Q.nsymbols symbols (R.frame_size), R.data_tones == Q.ncarriers, a multiple of 16.
 template <int L, int M, int QB>
 __device__ __forceinline__ void fused_modulate_round(const RawParams &R, const uint8_t *irow, const uint32_t (&ioff)[M],
                                                      bool active, int slot, int t, int lane, v2f *T, const v2f *T_wave,
@@ -1060,7 +1108,7 @@ k_raw_tx(RawParams R, QamTxParams Q, const uint8_t *__restrict__ data, float2 *_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < N; i += 64 * W) {
         const float2 w = R.tw[i];
-        s_tw[i] = (v2f){w.x, w.y};
+        s_tw[i] = (v2f){w.x, w.y} * raw_tw_factor<L, M>();
         s_src[i] = R.src[i];
     }
     fused_lut_fill<QB>(s_lut, Q.scale, tid, 64 * W);
@@ -1552,8 +1600,8 @@ int ofdmtx_raw_tx(ofdmtx_ctx *ctx, const ofdmtx_raw_plan *pl, int qambits, int n
     case 64: return launch_raw_tx<8, 8, 4>(ctx, rp, Q, key, d_bytes, iq, 0, st);
     case 128: return launch_raw_tx<8, 16, 4>(ctx, rp, Q, key, d_bytes, iq, 0, st);
     case 256: return launch_raw_tx<16, 16, 12>(ctx, rp, Q, key, d_bytes, iq, 0, st);
-    case 512: return launch_raw_tx<16, 32, 8>(ctx, rp, Q, key, d_bytes, iq, 0, st);
-    case 1024: return launch_raw_tx<32, 32, 6>(ctx, rp, Q, key, d_bytes, iq, 0, st);
+    case 512: return launch_raw_tx<64, 8, 16>(ctx, rp, Q, key, d_bytes, iq, 0, st);
+    case 1024: return launch_raw_tx<64, 16, 12>(ctx, rp, Q, key, d_bytes, iq, 0, st);
     default: return OFDMTX_ESHAPE;
     }
 }

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Experiment driver: the fused rawofdm kernel in its wave-local form (OFDMTX_RAW_TX_WAVE = rows per
-wave and pass, OFDMTX_RAW_TX_W = waves per workgroup) against the two-kernel path: bit identity, then
-time per launch.  usage: raw_tx_sweep.py [N ...]"""
+"""Experiment driver: rawofdm bytes -> IQ in one kernel against the two-kernel path (bit chain, then
+modulator): bit identity, then time per launch of the fused kernel and of the modulator alone.
+OFDMTX_LIB selects the library variant.  usage: raw_tx_sweep.py [N ...]"""
 import json
 import os
 import sys
@@ -52,28 +52,17 @@ def main():
             plan.modulate(vals, out=want)
             alg = data.numel() + plan.n_samples * 8
             iq = torch.empty_like(want)
-            combos = [(rd, w) for rd in (0, 2) for w in (2, 4, 6, 8, 12)]
-            if os.environ.get("SWEEP_DEFAULT_ONLY"):
-                combos = [(None, None)]
-            for rw, w in combos:
-                for k in ("OFDMTX_RAW_TX_ROUNDS", "OFDMTX_RAW_TX_W"):
-                    os.environ.pop(k, None)
-                if rw is not None:
-                    os.environ["OFDMTX_RAW_TX_ROUNDS"] = str(rw)
-                    os.environ["OFDMTX_RAW_TX_W"] = str(w)
-                iq.zero_()
-                try:
-                    mod.modulate_bytes(bitrate, data, nsym, out=iq)
-                except Exception as e:      # noqa: BLE001
-                    print(json.dumps({"N": nfft, "bitrate": bitrate, "rounds": rw, "W": w, "error": str(e)[:80]}), flush=True)
-                    continue
-                torch.cuda.synchronize()
-                same = bool(torch.equal(iq.view(torch.float32), want.view(torch.float32)))
-                ms = timed(lambda: mod.modulate_bytes(bitrate, data, nsym, out=iq))
-                print(json.dumps({"N": nfft, "bitrate": bitrate, "rounds": rw, "W": w, "fused": bool(mod.fused), "same": same,
-                                  "ms": round(ms, 4), "frac": round(alg / (ms * 1e-3) / 8e12, 4)}), flush=True)
-                if not same:
-                    return 1
+            iq.zero_()
+            mod.modulate_bytes(bitrate, data, nsym, out=iq)
+            torch.cuda.synchronize()
+            same = bool(torch.equal(iq.view(torch.float32), want.view(torch.float32)))
+            ms = timed(lambda: mod.modulate_bytes(bitrate, data, nsym, out=iq))
+            ms_mod = timed(lambda: plan.modulate(vals, out=want))
+            print(json.dumps({"N": nfft, "bitrate": bitrate, "fused": bool(mod.fused), "same": same, "ms": round(ms, 4),
+                              "frac": round(alg / (ms * 1e-3) / 8e12, 4), "modulator_ms": round(ms_mod, 4),
+                              "modulator_frac": round((vals.numel() + plan.n_samples) * 8 / (ms_mod * 1e-3) / 8e12, 4)}), flush=True)
+            if not same:
+                return 1
     return 0
 
 
