@@ -350,6 +350,15 @@ int ofdmtx_raw_plan_get_sizes(const ofdmtx_raw_plan *plan, ofdmtx_raw_sizes *out
  * d_iq: n_samples complex64. */
 int ofdmtx_raw_modulate(ofdmtx_ctx *ctx, const ofdmtx_raw_plan *plan, const float *d_data,
                         float *d_mapped, float *d_iq, void *stream);
+/* The other tap points of ofdm_mod's --log (raw_ofdm_mod.py:58-66), formed from d_mapped and d_iq
+ * of a finished ofdmtx_raw_modulate on the same stream; each output may be NULL.
+ * d_pre:  n_rows x fft_length, the preamble inserter's output ("tx-pre.dat": the mapped symbols with
+ *         the preamble symbols in front of every frame, frequency domain);
+ * d_ifft: n_rows x fft_length, gr.fft_vcc's output ("tx-ifft.dat");
+ * d_cp:   n_rows x (fft_length + cp_length), the prefixer's output ("tx-cp.dat"), i.e. d_iq before
+ *         the multiply_const block of :48. */
+int ofdmtx_raw_taps(ofdmtx_ctx *ctx, const ofdmtx_raw_plan *plan, const float *d_mapped,
+                    const float *d_iq, float *d_pre, float *d_ifft, float *d_cp, void *stream);
 
 /* rawofdm's bit chain in front of its mapper: qam_tx of rawofdm/src/python/raw_qam.py:76-102, i.e.
  * the blocks raw.conv_punc(framebytes, framebytes+1) (one zero byte of padding per frame),

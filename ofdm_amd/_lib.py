@@ -83,6 +83,7 @@ PROTOTYPES = {
     "ofdmtx_raw_plan_destroy": (C.c_int, [_VP]),
     "ofdmtx_raw_plan_get_sizes": (C.c_int, [_VP, C.POINTER(RawSizes)]),
     "ofdmtx_raw_modulate": (C.c_int, [_VP] * 6),
+    "ofdmtx_raw_taps": (C.c_int, [_VP] * 8),
     "ofdmtx_raw_framebytes": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_uint32)]),
     "ofdmtx_raw_tx": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int, _VP, _VP, _VP]),
     "ofdmtx_raw_qam_tx": (C.c_int, [_VP, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, _VP, C.c_uint64, _VP,

@@ -1192,6 +1192,45 @@ k_raw_tx(RawParams R, QamTxParams Q, const uint8_t *__restrict__ data, float2 *_
     }
 }
 
+// The tap points behind the mapper (rawofdm/src/python/raw_ofdm_mod.py:58-66), formed from what the
+// modulator wrote: the preamble inserter's output (mapped symbols and the given preamble symbols
+// in row order), the inverse transform's output (a row without its prefix, before the 1/sqrt(N)
+// block) and the prefixer's output (the rows before that block).  One workgroup per row.
+__global__ void __launch_bounds__(256)
+k_raw_taps(RawParams R, uint32_t n_rows, float unscale, const float2 *__restrict__ pre_freq,
+           const float2 *__restrict__ mapped, const float2 *__restrict__ iq, float2 *__restrict__ pre,
+           float2 *__restrict__ ifft, float2 *__restrict__ cp)
+{
+    const uint32_t row_len = R.n + R.cp;
+    const uint64_t n_items = (uint64_t)n_rows + (pre ? (uint64_t)R.n_sym + (uint64_t)R.n_frames * R.n_pre : 0u);
+    for (uint64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+        if (item < n_rows) {
+            const float2 *src = iq + item * row_len;
+            for (uint32_t i = threadIdx.x; i < row_len; i += 256) {
+                const float2 v = make_float2(src[i].x * unscale, src[i].y * unscale);
+                if (cp) cp[item * row_len + i] = v;
+                if (ifft && i >= R.cp) ifft[item * R.n + (i - R.cp)] = v;
+            }
+            continue;
+        }
+        uint64_t j = item - n_rows;
+        const float2 *src;
+        uint64_t row;
+        if (j < R.n_sym) {
+            row = R.frame_size ? (j / R.frame_size) * (R.frame_size + R.n_pre) + R.n_pre + j % R.frame_size
+                               : (R.sym_row[j] == ROW_DROPPED ? ~0ull : (uint64_t)R.sym_row[j]);
+            if (row == ~0ull) continue;
+            src = mapped + j * R.n;
+        } else {
+            j -= R.n_sym;
+            const uint64_t f = j / R.n_pre, k = j % R.n_pre;
+            row = (R.frame_size ? f * (R.frame_size + R.n_pre) : (uint64_t)R.frame_row[f]) + k;
+            src = pre_freq + k * R.n;
+        }
+        for (uint32_t i = threadIdx.x; i < R.n; i += 256) pre[row * R.n + i] = src[i];
+    }
+}
+
 }  // namespace
 
 struct ofdmtx_raw_plan {
@@ -1202,6 +1241,7 @@ struct ofdmtx_raw_plan {
     int16_t *d_src;
     float2 *d_tw;
     float2 *d_pre_rows;
+    float2 *d_pre_freq;          // the preamble symbols as given (n_pre x N bins): the "tx-pre.dat" tap
     uint32_t *d_sym_row;
     uint32_t *d_frame_row;
 };
@@ -1282,7 +1322,7 @@ int raw_plan_common(ofdmtx_ctx *ctx, uint32_t n, uint32_t cp, const int32_t *car
         }
     }
     if (d_ident) (void)hipFree(d_ident);
-    if (d_freq) (void)hipFree(d_freq);
+    pl->d_pre_freq = d_freq;
     if (e != hipSuccess || rc != OFDMTX_OK) {
         if (e != hipSuccess) {
             ofdmtx_g_last_hip = (int)e;
@@ -1458,6 +1498,7 @@ int ofdmtx_raw_plan_destroy(ofdmtx_raw_plan *pl)
     if (pl->d_src) (void)hipFree(pl->d_src);
     if (pl->d_tw) (void)hipFree(pl->d_tw);
     if (pl->d_pre_rows) (void)hipFree(pl->d_pre_rows);
+    if (pl->d_pre_freq) (void)hipFree(pl->d_pre_freq);
     if (pl->d_sym_row) (void)hipFree(pl->d_sym_row);
     if (pl->d_frame_row) (void)hipFree(pl->d_frame_row);
     delete pl;
@@ -1480,6 +1521,26 @@ int ofdmtx_raw_modulate(ofdmtx_ctx *ctx, const ofdmtx_raw_plan *pl, const float 
     HIPCHK(hipSetDevice(ctx->device));
     return launch_raw_n(ctx, pl->rp, reinterpret_cast<const float2 *>(d_data), reinterpret_cast<float2 *>(d_mapped),
                         reinterpret_cast<float2 *>(d_iq), (hipStream_t)stream);
+}
+
+int ofdmtx_raw_taps(ofdmtx_ctx *ctx, const ofdmtx_raw_plan *pl, const float *d_mapped, const float *d_iq, float *d_pre,
+                    float *d_ifft, float *d_cp, void *stream)
+{
+    if (!ctx || !pl || pl->ctx != ctx || !d_iq || (d_pre && !d_mapped && pl->rp.n_sym)) return OFDMTX_EINVAL;
+    if (!d_pre && !d_ifft && !d_cp) return OFDMTX_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint64_t n_rows = pl->sizes.n_rows;
+    const uint64_t items = n_rows + (d_pre ? pl->sizes.n_sym + (uint64_t)pl->rp.n_frames * pl->rp.n_pre : 0u);
+    if (items == 0) return OFDMTX_OK;
+    const uint64_t cap = (uint64_t)ctx->n_cu * 32u;
+    // the block multiplies by the float32 constant 1/sqrt(N) (raw_ofdm_mod.py:48); the taps sit in front of it
+    const float unscale = (float)sqrt((double)pl->rp.n);
+    hipLaunchKernelGGL(k_raw_taps, dim3((unsigned)(items < cap ? items : cap)), dim3(256), 0, (hipStream_t)stream, pl->rp,
+                       (uint32_t)n_rows, unscale, pl->d_pre_freq, reinterpret_cast<const float2 *>(d_mapped),
+                       reinterpret_cast<const float2 *>(d_iq), reinterpret_cast<float2 *>(d_pre),
+                       reinterpret_cast<float2 *>(d_ifft), reinterpret_cast<float2 *>(d_cp));
+    HIPCHK(hipGetLastError());
+    return OFDMTX_OK;
 }
 
 int ofdmtx_raw_framebytes(int qambits, int nc, int np, uint64_t size, uint32_t *out)

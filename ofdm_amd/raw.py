@@ -186,6 +186,17 @@ class RawPlan(object):
                                                  _stream(dev)))
         return (iq, mapped) if want_mapped else iq
 
+    def taps(self, mapped, iq):
+        """The tap points behind the mapper (rawofdm/src/python/raw_ofdm_mod.py:58-66) of a finished
+        modulate(..., want_mapped=True): {"pre": n_rows x N, "ifft": n_rows x N, "cp": n_samples}."""
+        dev = self.ctx.device
+        pre = torch.zeros((self.n_rows, self.fft_length), dtype=torch.complex64, device=dev)
+        ifft = torch.empty((self.n_rows, self.fft_length), dtype=torch.complex64, device=dev)
+        cp = torch.empty(self.n_samples, dtype=torch.complex64, device=dev)
+        _lib.check(self._lib.ofdmtx_raw_taps(self.ctx._h, self._h, _ptr(mapped), _ptr(iq), _ptr(pre), _ptr(ifft),
+                                             _ptr(cp), _stream(dev)))
+        return {"pre": pre, "ifft": ifft, "cp": cp}
+
 
 def _config_arrays(carrier_map, preambles, fft_length):
     cm = np.ascontiguousarray(carrier_map, dtype=np.int32)
@@ -229,9 +240,11 @@ class ofdm_mod(object):
         self._frame_plans = {}      # (n_frames, frame_size) -> RawPlan; a plan uploads tables and transforms the preambles
 
     def _finish(self, plan, data):
-        if self._log:                                               # raw_ofdm_mod.py:54-57 ("tx-map.dat")
+        if self._log:                                               # raw_ofdm_mod.py:54-66
             iq, mapped = plan.modulate(data, want_mapped=True)
             mapped.cpu().numpy().tofile("tx-map.dat")
+            for name, t in plan.taps(mapped, iq).items():
+                t.cpu().numpy().tofile("tx-%s.dat" % name)
             return iq
         return plan.modulate(data)
 

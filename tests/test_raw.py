@@ -213,6 +213,45 @@ def test_gpu_flags_match_oracle(txctx, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,cp", [(64, 16), (256, 7), (512, 128), (1024, 256)])
+def test_gpu_log_taps_match_oracle(txctx, tmp_path, monkeypatch, n, cp):
+    """tx-map / tx-pre / tx-ifft / tx-cp of ofdm_mod's --log (rawofdm/src/python/raw_ofdm_mod.py:54-66):
+    item sizes and contents against the oracle's intermediate results, ragged frames with dropped symbols."""
+    import torch
+    from ofdm_amd import raw
+    rng = np.random.default_rng(15)
+    opt = ro.Options(fft_length=n, occupied_tones=int(0.8125 * n), cp_length=cp, log=True)
+    p = ro.OfdmParams(opt)
+    flags = np.zeros(23, np.uint8)
+    flags[[2, 9, 22]] = 1
+    data = qpsk(rng, 23 * p.data_tones).reshape(23, -1)
+    mapped = ro.mapper(p.padded_carriers, data)
+    with_pre = ro.insert_preamble(mapped, flags, p.padded_preambles)
+    rows = ro.ifft_cp_scale(with_pre, cp) * np.sqrt(n)               # in front of the 1/sqrt(N) block
+    monkeypatch.chdir(tmp_path)
+    mod = raw.ofdm_mod(opt, ctx=txctx)
+    iq = mod.modulate(data, flags)
+    torch.cuda.synchronize()
+    assert iq.numel() == rows.size
+    got = {k: np.fromfile(str(tmp_path / ("tx-%s.dat" % k)), dtype=np.complex64) for k in ("map", "pre", "ifft", "cp")}
+    assert np.array_equal(got["map"].view(np.uint64), mapped.astype(np.complex64).reshape(-1).view(np.uint64))
+    assert np.array_equal(got["pre"].view(np.uint64), with_pre.astype(np.complex64).reshape(-1).view(np.uint64))
+    assert got["ifft"].size == rows.shape[0] * n and got["cp"].size == rows.size
+    assert rel_l2(got["cp"], rows, n + cp).max() <= REL_L2_TOL
+    assert rel_l2(got["ifft"], rows[:, cp:], n).max() <= REL_L2_TOL
+    # frames of equal size take the arithmetic row mapping
+    plan = raw.plan_frames(txctx, n, cp, p.padded_carriers, p.padded_preambles, 3, 4)
+    d2 = torch.from_numpy(data[:12].astype(np.complex64)).to(txctx.device).reshape(-1)
+    iq2, m2 = plan.modulate(d2, want_mapped=True)
+    taps = plan.taps(m2, iq2)
+    torch.cuda.synchronize()
+    want = ro.insert_preamble(mapped[:12], ro.frame_flags(3, 4), p.padded_preambles).astype(np.complex64)
+    assert np.array_equal(taps["pre"].cpu().numpy().view(np.uint64), want.view(np.uint64))
+    assert torch.equal((taps["ifft"].reshape(-1, n)).view(torch.float32),
+                       taps["cp"].reshape(-1, n + cp)[:, cp:].contiguous().view(torch.float32))
+
+
+@pytest.mark.gpu
 def test_gpu_no_flag_no_output(txctx):
     from ofdm_amd import raw
     p = ro.OfdmParams(ro.Options())
