@@ -44,6 +44,7 @@ extern "C" {
 #define OFDMTX_ETOOBIG (-7)   /* batch exceeds the 32-bit row index of the kernels, or the
                                  fixed capacity of an allocation-free entry point           */
 #define OFDMTX_EBUSY (-8)     /* a ragged plan is still running on another stream          */
+#define OFDMTX_ECOMM (-9)     /* RCCL missing or an RCCL call failed; ofdmtx_last_comm_error() */
 
 /* plan flags */
 #define OFDMTX_F_PREAMBLE 1u  /* prepend the 4x80-sample preamble (ftw/ftw_ofdm_preamble.cc:79-83) */
@@ -388,6 +389,32 @@ int ofdmtx_raw_qam_tx(ofdmtx_ctx *ctx, int qambits, int nc, int np, uint32_t nca
  * instead. */
 int ofdmtx_raw_tx(ofdmtx_ctx *ctx, const ofdmtx_raw_plan *plan, int qambits, int nc, int np,
                   const uint8_t *d_bytes, float *d_iq, void *stream);
+
+/* ---- optional exchange: the ranks' IQ shards into one buffer on a root GPU -----------------------
+ * Packets are sharded over GPUs by index and nothing on the transmit path needs another rank's
+ * data; this is for a consumer that wants ONE stream, as the reference's flowgraph ends in one sink
+ * (ftw_80211_ofdm_tx/src/examples/ftw_ofdm_tx_uhd.py:83-92: a single file sink or USRP sink behind
+ * ofdm_mod).  One process per GPU; point-to-point over RCCL: every peer sends its shard to the root,
+ * the root posts all receives as one group, so the peers' transfers run side by side on their own
+ * xGMI links.  librccl is looked up at the first call (not linked): OFDMTX_ECOMM when it is absent.
+ *
+ * ofdmtx_comm_unique_id: rank 0 makes the 128-byte id and hands it to the other ranks by its own means
+ *   (file, socket, MPI, a torch.distributed store); ofdmtx_comm_create is collective over the
+ *   `world` ranks with that id, each on its own context/device.
+ * ofdmtx_gather: collective, enqueued on `stream` (may be called per chunk of a shard, on a side
+ *   stream, while the kernels produce the next chunk).  d_src: this rank's n_samples complex64.  On the root:
+ *   d_dst receives rank r's samples at sample offset sample_off[r] (host array of world + 1
+ *   ascending offsets; sample_off[root + 1] - sample_off[root] must equal n_samples); the root's own
+ *   shard is copied unless d_src already is d_dst + 2 * sample_off[root].  Other ranks pass d_dst =
+ *   sample_off = NULL.  Ranks with n_samples == 0 exchange nothing. */
+#define OFDMTX_COMM_ID_BYTES 128
+typedef struct ofdmtx_comm ofdmtx_comm;
+int ofdmtx_comm_unique_id(void *id);
+int ofdmtx_comm_create(ofdmtx_ctx *ctx, int rank, int world, const void *id, ofdmtx_comm **out);
+int ofdmtx_comm_destroy(ofdmtx_comm *comm);
+int ofdmtx_gather(ofdmtx_comm *comm, const float *d_src, uint64_t n_samples, float *d_dst,
+                  const uint64_t *sample_off, int root, void *stream);
+int ofdmtx_last_comm_error(void);   /* ncclResult_t of the last failing RCCL call on this thread */
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OFDMTX_LIB", os.path.join(_HERE, "libofdmtx.so"))
 
 OK = 0
-EINVAL, EREGIME, ELENGTH, EHIP, ENOMEM, ESHAPE, ETOOBIG, EBUSY = -1, -2, -3, -4, -5, -6, -7, -8
+EINVAL, EREGIME, ELENGTH, EHIP, ENOMEM, ESHAPE, ETOOBIG, EBUSY, ECOMM = -1, -2, -3, -4, -5, -6, -7, -8, -9
 F_PREAMBLE, F_ZEROGAP, F_SWAPIQ, F_PNC_A, F_PNC_B = 1, 2, 4, 8, 16
 PILOT_REF_STREAM, PILOT_PER_PACKET, PILOT_PNC_A, PILOT_PNC_B, PILOT_PNC_ALL = 0, 1, 2, 3, 4
 # status bits of the loop-back verifier (ofdmtx_rx_demod / ofdmtx_rx_decode)
@@ -84,6 +84,11 @@ PROTOTYPES = {
     "ofdmtx_raw_plan_get_sizes": (C.c_int, [_VP, C.POINTER(RawSizes)]),
     "ofdmtx_raw_modulate": (C.c_int, [_VP] * 6),
     "ofdmtx_raw_taps": (C.c_int, [_VP] * 8),
+    "ofdmtx_comm_unique_id": (C.c_int, [_VP]),
+    "ofdmtx_comm_create": (C.c_int, [_VP, C.c_int, C.c_int, _VP, C.POINTER(_VP)]),
+    "ofdmtx_comm_destroy": (C.c_int, [_VP]),
+    "ofdmtx_gather": (C.c_int, [_VP, _VP, C.c_uint64, _VP, _VP, C.c_int, _VP]),
+    "ofdmtx_last_comm_error": (C.c_int, []),
     "ofdmtx_raw_framebytes": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_uint32)]),
     "ofdmtx_raw_tx": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int, _VP, _VP, _VP]),
     "ofdmtx_raw_qam_tx": (C.c_int, [_VP, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, _VP, C.c_uint64, _VP,
@@ -119,6 +124,8 @@ def check(rc):
         msg = lib.ofdmtx_strerror(rc).decode()
         if rc == EHIP:
             msg += " (hipError %d)" % lib.ofdmtx_last_hip_error()
+        if rc == ECOMM:
+            msg += " (ncclResult %d)" % lib.ofdmtx_last_comm_error()
         if rc == ELENGTH:
             raise ValueError("MPDU-length must be in [0, 3168]")      # ftw_packet_utils.py:119-121
         raise OfdmTxError(rc, msg)

@@ -1279,6 +1279,7 @@ const char *ofdmtx_strerror(int code)
     case OFDMTX_ESHAPE: return "block shape not supported (802.11a needs 48 data carriers, 64-point FFT)";
     case OFDMTX_ETOOBIG: return "batch too large for one launch";
     case OFDMTX_EBUSY: return "ragged plan still running on another stream";
+    case OFDMTX_ECOMM: return "RCCL not available or an RCCL call failed";
     default: return "unknown error";
     }
 }

@@ -9,9 +9,13 @@ at the number of symbols in all earlier packets.  `gather_iq` is the optional ex
 that collects the shards' IQ into one buffer on a root rank (RCCL over xGMI when the tensors
 live on GPUs, gloo on CPU tensors).
 """
+import ctypes as C
+
 import numpy as np
 import torch
 import torch.distributed as dist
+
+from . import _lib
 
 
 def shard_bounds(n_pkts, world, rank):
@@ -193,3 +197,58 @@ def gather_chunked(produce, chunk_samples, dst=0, group=None, out=None, device=N
     if gpu:
         compute.wait_stream(side)
     return None
+
+
+class Comm(object):
+    """The exchange step at the C ABI (include/ofdmtx.h, ofdmtx_comm_* / ofdmtx_gather): one RCCL
+    communicator per rank, for hosts that do not run torch.distributed.  Rank 0 calls
+    Comm.unique_id() and hands the 128 bytes to the other ranks; every rank then constructs
+    Comm(ctx, rank, world, uid) (collective)."""
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        _lib.check(_lib.load().ofdmtx_comm_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, ctx, rank, world, uid):
+        if len(uid) != 128:
+            raise ValueError("the communicator id has 128 bytes")
+        self.ctx, self.rank, self.world = ctx, int(rank), int(world)
+        h = C.c_void_p()
+        _lib.check(ctx._lib.ofdmtx_comm_create(ctx._h, self.rank, self.world, C.c_char_p(uid), C.byref(h)))
+        self._h = h
+
+    def gather(self, src, sample_off=None, out=None, root=0, stream=None):
+        """src: this rank's complex64 samples on the context's device.  On `root`: sample_off = the
+        world + 1 ascending sample offsets of the ranks' shards in `out` (allocated when None);
+        returns `out` there, None elsewhere.  Enqueued on `stream` (default: the current one)."""
+        dev = self.ctx.device
+        if src.dtype != torch.complex64 or src.device != dev or not src.is_contiguous():
+            raise ValueError("src must be a contiguous complex64 tensor on %s" % dev)
+        st = C.c_void_p((stream or torch.cuda.current_stream(dev)).cuda_stream)
+        if self.rank != root:
+            _lib.check(self.ctx._lib.ofdmtx_gather(self._h, C.c_void_p(src.data_ptr()), src.numel(), None, None,
+                                                   int(root), st))
+            return None
+        off = np.ascontiguousarray(sample_off, dtype=np.uint64)
+        if off.shape != (self.world + 1,):
+            raise ValueError("sample_off needs world + 1 entries")
+        if out is None:
+            out = torch.empty(int(off[-1]), dtype=torch.complex64, device=dev)
+        elif out.numel() < int(off[-1]) or out.dtype != torch.complex64 or out.device != dev or not out.is_contiguous():
+            raise ValueError("gather buffer must be contiguous complex64 on %s with >= %d samples" % (dev, int(off[-1])))
+        _lib.check(self.ctx._lib.ofdmtx_gather(self._h, C.c_void_p(src.data_ptr()), src.numel(),
+                                               C.c_void_p(out.data_ptr()), off.ctypes.data, int(root), st))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.ctx._lib.ofdmtx_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,7 +1,8 @@
 """One rank of tests/test_dist_gpu.py: started as a fresh process (before anything touches the GPU),
 joins a gloo group with its sibling, produces its packet range with the HIP kernels in chunks
 through ofdm_amd.dist.gather_chunked, and -- on rank 0 -- compares the gathered stream with ONE launch
-over the whole batch.  The ranks share GPU 0 (the box has one); with RCCL each would own a GPU."""
+over the whole batch.  The ranks share GPU 0 (the box has one); with OFDM_TEST_BACKEND=nccl each rank owns GPU `rank`
+and the chunks travel over RCCL."""
 import os
 import sys
 
@@ -19,10 +20,16 @@ from ofdm_amd.batch import TxContext  # noqa: E402
 
 def main():
     mode, n_chunks = sys.argv[1], int(sys.argv[2])
-    dist.init_process_group("gloo")
-    rank, world = dist.get_rank(), dist.get_world_size()
-    torch.cuda.set_device(0)
-    ctx = TxContext(0)
+    backend = os.environ.get("OFDM_TEST_BACKEND", "gloo")
+    rank = int(os.environ["RANK"])
+    dev = rank if backend == "nccl" else 0               # RCCL: one GPU per rank; gloo: the ranks share GPU 0
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group("gloo")
+    world = dist.get_world_size()
+    ctx = TxContext(dev)
     rng = np.random.default_rng(99)                      # the same batch in every rank
     n = 203
     if mode == "uniform":
