@@ -536,50 +536,24 @@ struct RowWalk {
     }
 };
 
-// GROUPED (ncarriers a multiple of 16): a thread takes the QB units behind carriers c', c' + G,
+// Carrier counts that are a multiple of 16: a lane takes the QB units behind carriers c', c' + G,
 // .. c' + 15 G (G = ncarriers / 16) -- they are the 16 bit positions of the same units -- so every
 // bit position, rotation and shift below is a compile-time constant.  The units are never
-// materialised: the encoder leaves its two output streams A and B (one bit per input bit each)
-// as separate MSB-first word rows, and bit b of unit m is looked up where puncturing took it from:
+// materialised: the encoder's two output streams A and B (one bit per input bit each) stay
+// separate, and bit b of unit m is looked up where puncturing took it from:
 //   rate 1/2 (keep 4 of 4): punctured bit k = coded bit k      -> stream b & 1, input bit 8 m + b / 2
 //   rate 3/4 (keep 4 of 6): coded bit 6 (k / 4) + k % 4         -> stream b & 1, input bit 12 m + 3 (b / 4) + (b % 4) / 2
 //   rate 2/3 (keep 3 of 4): coded bit 4 (k / 3) + k % 3, k = 16 m + b; three units span 32 input bits
 //                            -> with j = 16 (m % 3) + b: stream (j % 3) & 1, input bit 32 (m / 3) + 2 (j / 3) + (j % 3) / 2
-// (rawofdm/src/lib/qam/raw_conv.cc:150-159).  A thread first loads the stream pieces behind its
-// QB units: QB bytes, QB 12-bit windows, or -- rate 2/3, where QB = 6 makes m % 3 = u % 3 -- two words.
+// (rawofdm/src/lib/qam/raw_conv.cc:150-159).  The lane keeps the stream pieces behind its QB units:
+// QB bytes, QB 12-bit windows, or -- rate 2/3, where QB = 6 makes m % 3 = u % 3 -- two words.
 template <int QB, int NC, int NP>
 struct UnitBits {
     static constexpr int NPIECE = (NC == 4 && NP == 3) ? 2 : (QB == 1 ? 1 : QB);
     uint32_t a[NPIECE], b[NPIECE];
 
-    __device__ __forceinline__ void load(const uint32_t *SA, const uint32_t *SB, uint32_t cprime)
-    {
-        if constexpr (NC == 4 && NP == 4) {
-            const uint8_t *ba = reinterpret_cast<const uint8_t *>(SA), *bb = reinterpret_cast<const uint8_t *>(SB);
-#pragma unroll
-            for (int u = 0; u < QB; u++) {
-                const uint32_t m = (uint32_t)QB * cprime + (uint32_t)u;       // byte m of an MSB-first word row
-                a[u] = ba[m ^ 3u];
-                b[u] = bb[m ^ 3u];
-            }
-        } else if constexpr (NC == 6) {
-#pragma unroll
-            for (int u = 0; u < QB; u++) {
-                const uint32_t off = 12u * ((uint32_t)QB * cprime + (uint32_t)u), i = off >> 5, sh = off & 31u;
-                a[u] = (sh ? __funnelshift_l(SA[i + 1], SA[i], sh) : SA[i]) >> 20;
-                b[u] = (sh ? __funnelshift_l(SB[i + 1], SB[i], sh) : SB[i]) >> 20;
-            }
-        } else {
-            static_assert(QB == 6, "rate 2/3 is tabulated for 64-QAM only");
-            a[0] = SA[2u * cprime];
-            a[1] = SA[2u * cprime + 1u];
-            b[0] = SB[2u * cprime];
-            b[1] = SB[2u * cprime + 1u];
-        }
-    }
-
-    // The same pieces without any staging: the QB units of one group of 16 carriers are punctured
-    // bits 16 QB c' .. of the symbol, i.e. a run of IN_BITS = 8 QB NC / NP input bits that starts on a
+    // The QB units of one group of 16 carriers are punctured bits 16 QB c' .. of the symbol, i.e. a
+    // run of IN_BITS = 8 QB NC / NP input bits that starts on a
     // byte boundary (for every rate of raw_qam.py:19-28 but (1, (6, 4)), marked "DONT USE" there): the
     // lane fetches those bytes and the byte in front (the encoder's six bits of history), encodes
     // them itself (raw_conv.cc:46-51) and cuts its pieces out of the two streams.
@@ -762,10 +736,9 @@ struct QamWalks {
 };
 
 // Frame bytes -> punctured coded bits of rows row0 .. row0 + rows_here - 1 in B.pun (stride: the coded
-// stride at rate 1/2, else the punctured one).  SPLIT: no interleaving of the encoder's outputs and
-// no puncturing pass -- stream A goes to B.cod, stream B to B.pun, one word per 32 input bits each
-// (for UnitBits).  Called by every thread of the workgroup; starts and ends with a barrier.
-template <int NC, int NP, bool SPLIT>
+// stride at rate 1/2, else the punctured one).  Called by every thread of the workgroup; starts and
+// ends with a barrier.
+template <int NC, int NP>
 __device__ __forceinline__ void qam_rows_to_punctured(const QamTxParams &Q, const uint8_t *__restrict__ data,
                                                       uint64_t row0, uint32_t rows_here, const QamBufs &B,
                                                       const QamWalks &wk, uint32_t in_per_row)
@@ -840,16 +813,11 @@ __device__ __forceinline__ void qam_rows_to_punctured(const QamTxParams &Q, cons
         const uint32_t y4 = __funnelshift_r(cur, prev, 4), y5 = __funnelshift_r(cur, prev, 5);
         const uint32_t y6 = __funnelshift_r(cur, prev, 6);
         const uint32_t aw = cur ^ y3 ^ y4 ^ y5 ^ y6, bw = cur ^ y1 ^ y3 ^ y4 ^ y6;
-        if constexpr (SPLIT) {
-            B.cod[w.r * B.cod_stride + w.x] = aw;
-            B.pun[w.r * B.pun_stride + w.x] = bw;
-        } else {
-            const uint64_t both = (spread_bits(aw) << 1) | spread_bits(bw);     // A before B, MSB first
-            B.cod[w.r * B.cod_stride + 2u * w.x] = (uint32_t)(both >> 32);
-            B.cod[w.r * B.cod_stride + 2u * w.x + 1u] = (uint32_t)both;
-        }
+        const uint64_t both = (spread_bits(aw) << 1) | spread_bits(bw);         // A before B, MSB first
+        B.cod[w.r * B.cod_stride + 2u * w.x] = (uint32_t)(both >> 32);
+        B.cod[w.r * B.cod_stride + 2u * w.x + 1u] = (uint32_t)both;
     }
-    if constexpr (NP != NC && !SPLIT) {
+    if constexpr (NP != NC) {
         __syncthreads();
         // ---- puncturing: 4 words -> 3 (keep 3 of 4) or 3 words -> 2 (keep 4 of 6) per thread
         for (RowWalk w = wk.pun; w.r < rows_here; w.next()) {
@@ -871,18 +839,6 @@ __device__ __forceinline__ void qam_rows_to_punctured(const QamTxParams &Q, cons
     __syncthreads();
 }
 
-// The 16 carriers c', c' + G, .. c' + 15 G of a row (G = ncarriers / 16) from the row's two coded
-// streams: one level-index byte per carrier into idx_row (the row's ncarriers bytes).
-template <int QB, int NC, int NP>
-__device__ __forceinline__ void qam_group_to_idx(const uint32_t *SA, const uint32_t *SB, uint32_t cprime, uint32_t G,
-                                                 uint8_t *idx_row)
-{
-    constexpr int S = QB / 2 > 1 ? QB / 2 : 1;
-    UnitBits<QB, NC, NP> ub;
-    ub.load(SA, SB, cprime);
-    emit_unit_group<QB, NC, NP, S>(ub, idx_row + cprime, G, std::make_integer_sequence<int, 16>{});
-}
-
 // rawofdm/src/lib/qam/raw_qam.cc:63-74: level of an axis index (first bit = MSB), S bits per axis
 __device__ __forceinline__ float qam_level(uint32_t idx, uint32_t S, float scale)
 {
@@ -895,7 +851,7 @@ __device__ __forceinline__ float qam_level(uint32_t idx, uint32_t S, float scale
     return (float)pt * scale;
 }
 
-template <int QB, int NC, int NP, bool GROUPED>
+template <int QB, int NC, int NP>
 __global__ void __launch_bounds__(256) k_raw_qam_tx_fast(QamTxParams Q, const uint8_t *__restrict__ data,
                                                          float2 *__restrict__ out, uint32_t in_stride,
                                                          uint32_t cod_stride, uint32_t pun_stride,
@@ -906,21 +862,17 @@ __global__ void __launch_bounds__(256) k_raw_qam_tx_fast(QamTxParams Q, const ui
     extern __shared__ uint32_t s_qam[];
     uint32_t *s_in = s_qam;                                       // frame bytes behind the rows, MSB-first words
     uint32_t *s_cod = s_in + in_stride * rows_per_iter;           // coded bits of the rows, MSB first
-    // (GROUPED: s_cod / s_pun hold the encoder's streams A / B, always two areas)
-    constexpr bool ONE_AREA = NP == NC && !GROUPED;
+    constexpr bool ONE_AREA = NP == NC;
     uint32_t *s_pun = ONE_AREA ? s_cod : s_cod + cod_stride * rows_per_iter;
     const uint32_t p_stride = ONE_AREA ? cod_stride : pun_stride;
     uint32_t *s_row = s_cod + cod_stride * rows_per_iter + (ONE_AREA ? 0u : pun_stride * rows_per_iter);   // 4 words per row
     uint16_t *s_g = reinterpret_cast<uint16_t *>(s_row + 4u * rows_per_iter);
-    // GROUPED: no group table; the level indices of the pass, one byte per carrier value
-    uint8_t *s_idx = reinterpret_cast<uint8_t *>(s_row + 4u * rows_per_iter);
     __shared__ float s_lv[8];
     const uint32_t col = Q.cbps / 16u, n_groups = Q.cbps / S;
-    if constexpr (!GROUPED)
-        for (uint32_t g = threadIdx.x; g < n_groups; g += blockDim.x) {
-            const uint32_t i0 = S * g, b = i0 / col;
-            s_g[g] = (uint16_t)(((i0 - b * col) << 4) | b);       // first unit of the group, bit position
-        }
+    for (uint32_t g = threadIdx.x; g < n_groups; g += blockDim.x) {
+        const uint32_t i0 = S * g, b = i0 / col;
+        s_g[g] = (uint16_t)(((i0 - b * col) << 4) | b);           // first unit of the group, bit position
+    }
     if (threadIdx.x < (1u << S)) s_lv[threadIdx.x] = qam_level(threadIdx.x, S, Q.scale);
 
     const uint64_t n_rows = Q.n_values / Q.ncarriers;
@@ -931,29 +883,13 @@ __global__ void __launch_bounds__(256) k_raw_qam_tx_fast(QamTxParams Q, const ui
     const uint32_t units = (cod_per_row + 32u * PIN - 1u) / (32u * PIN);
     const QamWalks walks = {RowWalk(threadIdx.x, blockDim.x, in_stride), RowWalk(threadIdx.x, blockDim.x, words_per_row),
                             RowWalk(threadIdx.x, blockDim.x, units)};
-    const RowWalk walk_car(threadIdx.x, blockDim.x, GROUPED ? Q.ncarriers / 16u : Q.ncarriers);
+    const RowWalk walk_car(threadIdx.x, blockDim.x, Q.ncarriers);
     const QamBufs bufs = {s_in, s_cod, s_pun, s_row, in_stride, cod_stride, pun_stride};
     for (uint64_t row0 = (uint64_t)blockIdx.x * rows_per_iter; row0 < n_rows; row0 += (uint64_t)gridDim.x * rows_per_iter) {
         const uint32_t rows_here = n_rows - row0 < rows_per_iter ? (uint32_t)(n_rows - row0) : rows_per_iter;
-        qam_rows_to_punctured<NC, NP, GROUPED>(Q, data, row0, rows_here, bufs, walks, in_per_row);
+        qam_rows_to_punctured<NC, NP>(Q, data, row0, rows_here, bufs, walks, in_per_row);
         // ---- interleaver + QAM, one thread per carrier value
         float2 *orow = out + row0 * Q.ncarriers;
-        if constexpr (GROUPED) {
-            const uint32_t G = Q.ncarriers / 16u;
-            for (RowWalk w = walk_car; w.r < rows_here; w.next()) {
-                qam_group_to_idx<QB, NC, NP>(s_cod + w.r * cod_stride, s_pun + w.r * pun_stride, w.x, G,
-                                             s_idx + w.r * Q.ncarriers);
-            }
-            __syncthreads();
-            // two values per thread: 16-byte stores, consecutive over the workgroup
-            const uint32_t n_val = rows_here * Q.ncarriers;       // even: ncarriers is a multiple of 16
-            const __amdgpu_buffer_rsrc_t win = iq_window(orow);
-            for (uint32_t i = 2u * threadIdx.x; i < n_val; i += 2u * blockDim.x) {
-                const uint32_t v = *reinterpret_cast<const uint16_t *>(s_idx + i), v0 = v & 0xFFu, v1 = v >> 8;
-                iq_store(win, i / 2u, make_float4(s_lv[v0 >> 3], QB == 1 ? 0.f : s_lv[v0 & 7u], s_lv[v1 >> 3],
-                                                              QB == 1 ? 0.f : s_lv[v1 & 7u]));
-            }
-        } else
         for (RowWalk w = walk_car; w.r < rows_here; w.next()) {
             // unit m of the MSB-first stream is the 16-bit element m ^ 1 of the little-endian words
             const uint16_t *H = reinterpret_cast<const uint16_t *>(s_pun + w.r * p_stride);
@@ -1192,6 +1128,91 @@ k_raw_tx(RawParams R, QamTxParams Q, const uint8_t *__restrict__ data, float2 *_
     }
 }
 
+// ---- the bit chain alone in the wave-local form of k_raw_tx: bytes -> carrier values.  A lane takes a
+// group of 16 carriers (its input bytes straight from memory, encoded in registers, index bytes by
+// table), the wave's index bytes of a pass lie in LDS in carrier order, and the wave writes the values
+// of the pass -- consecutive symbols, so one contiguous run -- with 16 bytes per lane.  No wave waits
+// for another; the input of the next pass is fetched before the values of this one are written.
+// Needs ncarriers % 16 == 0 and a rate whose groups start on byte boundaries (all but (1, (6, 4))).
+template <int W, int QB, int NC, int NP>
+__global__ void __launch_bounds__(64 * W)
+k_raw_qam_wave(QamTxParams Q, const uint8_t *__restrict__ data, float2 *__restrict__ out, uint32_t rows_wave)
+{
+    using Units = UnitBits<QB, NC, NP>;
+    using GLut = GroupLut<QB, NC, NP>;
+    extern __shared__ __align__(16) unsigned char s_raw[];
+    __shared__ v2f s_lut[FUSED_LUT];
+    __shared__ uint32_t s_glut[GLut::WORDS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    fused_lut_fill<QB>(s_lut, Q.scale, tid, 64 * W);
+    GLut::fill(s_glut, tid, 64 * W);
+    __syncthreads();                                              // the only workgroup barrier
+
+    uint8_t *idx_wave = s_raw + (size_t)wave * rows_wave * Q.ncarriers;
+    const uint32_t G = Q.ncarriers / 16u;
+    const uint32_t sym_bytes = G * Units::IN_BYTES;               // input bytes behind one symbol
+    const SmallDiv gdiv(G), fdiv(Q.nsymbols);
+    uint32_t g_row[FUSED_IT], g_c[FUSED_IT];                      // the lane's groups of a pass: (row, c')
+#pragma unroll
+    for (int it = 0; it < FUSED_IT; it++) gdiv.divmod((uint32_t)lane + 64u * it, g_row[it], g_c[it]);
+
+    const uint32_t n_rows = (uint32_t)(Q.n_values / Q.ncarriers);
+    const uint32_t n_items = (n_rows + rows_wave - 1u) / rows_wave;
+    const uint32_t step = gridDim.x * W;
+    typename Units::Raw raw[FUSED_IT];
+    auto fetch_pass = [&](uint32_t row0) {
+        const uint32_t rows_here = n_rows - row0 < rows_wave ? n_rows - row0 : rows_wave;
+        const uint32_t f0 = row0 / Q.nsymbols, s0 = row0 - f0 * Q.nsymbols;          // wave-uniform
+#pragma unroll
+        for (int it = 0; it < FUSED_IT; it++) {
+            if (g_row[it] < rows_here) {
+                uint32_t f, sf;
+                fdiv.divmod(s0 + g_row[it], f, sf);
+                const uint8_t *p = data + (size_t)(f0 + f) * Q.frame_bytes + sf * sym_bytes + g_c[it] * (uint32_t)Units::IN_BYTES;
+                Units::fetch(raw[it], p, (sf | g_c[it]) != 0u, !(sf == Q.nsymbols - 1u && g_c[it] == G - 1u));
+            }
+        }
+    };
+    uint32_t item = blockIdx.x * W + wave;
+    if (item < n_items) fetch_pass(item * rows_wave);
+    for (; item < n_items; item += step) {
+        const uint32_t row0 = item * rows_wave;
+        const uint32_t rows_here = n_rows - row0 < rows_wave ? n_rows - row0 : rows_wave;
+        wave_sync();                                              // the previous pass has been written out
+#pragma unroll
+        for (int it = 0; it < FUSED_IT; it++) {
+            if (g_row[it] < rows_here) {
+                Units ub;
+                ub.encode(raw[it]);
+                uint8_t *irow = idx_wave + g_row[it] * Q.ncarriers + g_c[it];
+                if constexpr (GLut::USED) {
+                    uint32_t w4[4];
+                    GLut::emit(ub, s_glut, w4);
+                    // byte kk of word (s, h) is the carrier at bit position 8 h + 2 kk + s: carrier c' + G (8 h + 2 kk + s)
+#pragma unroll
+                    for (int sbit = 0; sbit < 2; sbit++)
+#pragma unroll
+                        for (int h = 0; h < 2; h++)
+#pragma unroll
+                            for (int kk = 0; kk < 4; kk++)
+                                irow[(uint32_t)(8 * h + 2 * kk + sbit) * G] = (uint8_t)(w4[2 * sbit + h] >> (8 * kk));
+                } else {
+                    emit_unit_group<QB, NC, NP, (QB / 2 > 1 ? QB / 2 : 1)>(ub, irow, G, std::make_integer_sequence<int, 16>{});
+                }
+            }
+        }
+        wave_sync();                                              // index bytes complete
+        if (item + step < n_items) fetch_pass((item + step) * rows_wave);
+        const uint32_t n_pairs = rows_here * Q.ncarriers / 2u;    // (ncarriers is even)
+        const __amdgpu_buffer_rsrc_t win = iq_window(out + (size_t)row0 * Q.ncarriers);
+        for (uint32_t i = lane; i < n_pairs; i += 64u) {
+            const uint32_t v = *reinterpret_cast<const uint16_t *>(idx_wave + 2u * i);
+            const v2f a = s_lut[v & 0xFFu], b = s_lut[v >> 8];
+            iq_store(win, i, make_float4(a.x, a.y, b.x, b.y));
+        }
+    }
+}
+
 // The tap points behind the mapper (rawofdm/src/python/raw_ofdm_mod.py:58-66), formed from what the
 // modulator wrote: the preamble inserter's output (mapped symbols and the given preamble symbols
 // in row order), the inverse transform's output (a row without its prefix, before the 1/sqrt(N)
@@ -1397,6 +1418,28 @@ static int launch_raw_tx(const ofdmtx_ctx *ctx, const RawParams &rp, const QamTx
     return OFDMTX_OK;
 }
 
+// launch of the wave-local bit chain; false if this rate cannot take it
+template <int QB, int NC, int NP>
+static bool launch_qam_wave(const ofdmtx_ctx *ctx, const QamTxParams &Q, const uint8_t *d_bytes, float2 *out, hipStream_t st)
+{
+    if constexpr ((8 * QB * NC / NP) % 8 != 0) {
+        return false;                                             // (1, (6, 4)): a group's input is a byte and a half
+    } else {
+        constexpr int W = 8;
+        const uint32_t G = Q.ncarriers / 16u;
+        const uint32_t rows_wave = 64u * FUSED_IT / G;
+        const size_t lds = (size_t)W * rows_wave * Q.ncarriers;
+        const uint64_t n_rows = Q.n_values / Q.ncarriers;
+        const uint64_t n_items = (n_rows + rows_wave - 1) / rows_wave;
+        uint64_t blocks = (n_items + W - 1) / W;
+        const uint64_t cap = (uint64_t)ctx->n_cu * 4u;
+        if (blocks > cap) blocks = cap;
+        hipLaunchKernelGGL((k_raw_qam_wave<W, QB, NC, NP>), dim3((unsigned)blocks), dim3(64 * W), lds, st, Q, d_bytes, out,
+                           rows_wave);
+        return true;
+    }
+}
+
 // fills the bit chain's parameters (shared by ofdmtx_raw_qam_tx and ofdmtx_raw_tx)
 static int qam_params(int qambits, int nc, int np, uint32_t ncarriers, uint32_t nsymbols, uint64_t n_frames, QamTxParams *Q)
 {
@@ -1575,25 +1618,23 @@ int ofdmtx_raw_qam_tx(ofdmtx_ctx *ctx, int qambits, int nc, int np, uint32_t nca
     const unsigned grid = (unsigned)(n_iters < cap ? n_iters : cap);
     hipStream_t st = (hipStream_t)stream;
     float2 *o2 = reinterpret_cast<float2 *>(d_out);
-    // table entries of raw_qam.py:19-28: the structured kernel (see k_raw_qam_tx_fast)
+    // table entries of raw_qam.py:19-28.  Whole groups of 16 carriers per lane (at most 64 * FUSED_IT
+    // groups per symbol, 16-byte stores): the wave-local form, k_raw_qam_wave; other carrier counts:
+    // the workgroup form, k_raw_qam_tx_fast
     const uint32_t cod_bits = Q.cbps / (uint32_t)np * (uint32_t)nc;
-    // rows per pass: the grouped form keeps one thread per 16 carriers busy, so it wants 16x the rows
-    const bool grouped = ncarriers % 16u == 0 && ((uintptr_t)d_out & 15u) == 0;      // it stores 16 bytes at a time
-    // per-carrier form: interleaved coded words (the puncturing pass reads whole units) and punctured
-    // words; grouped form: the two encoder streams, one word per 32 input bits each, plus the word
-    // a 12-bit window may reach into
-    const uint32_t stream_words = (cod_bits + 63u) / 64u + 1u;
-    const uint32_t cod_stride = grouped ? stream_words : cod_words + 4u;
-    const uint32_t pun_stride = grouped ? stream_words
-                                        : nc == np ? 0u : nc == 4 ? 3u * ((cod_bits + 127u) / 128u) : 2u * ((cod_bits + 95u) / 96u);
+    const bool wave_ok = ncarriers % 16u == 0 && ((uintptr_t)d_out & 15u) == 0 && ncarriers / 16u <= 64u * FUSED_IT &&
+                         n_rows < 0xFFFFFFF0ull;
+    // interleaved coded words (the puncturing pass reads whole units) and punctured words
+    const uint32_t cod_stride = cod_words + 4u;
+    const uint32_t pun_stride = nc == np ? 0u : nc == 4 ? 3u * ((cod_bits + 127u) / 128u) : 2u * ((cod_bits + 95u) / 96u);
     // staged input per row: 4 bytes ahead of the row's first input bit, the row's input bits, slack
     // for a bit offset and the word read past the end
     const uint32_t in_stride = (cod_bits / 2u + 31u) / 32u + 4u;
     const uint32_t row_words = in_stride + cod_stride + pun_stride + 4u;
-    uint32_t rows_fast = grouped ? (4096u + ncarriers - 1u) / ncarriers : rows_per_iter;
-    // behind the rows: the group table (cbps / s entries), or in the grouped form one byte per value
-    const size_t tail_fixed = grouped ? 0 : (size_t)(Q.cbps / s) * sizeof(uint16_t);
-    const size_t row_bytes = row_words * sizeof(uint32_t) + (grouped ? ncarriers : 0u);
+    uint32_t rows_fast = rows_per_iter;
+    // behind the rows: the group table (cbps / s entries)
+    const size_t tail_fixed = (size_t)(Q.cbps / s) * sizeof(uint16_t);
+    const size_t row_bytes = row_words * sizeof(uint32_t);
     const uint32_t rows_fit = tail_fixed < 40000u ? (uint32_t)((48000u - tail_fixed) / row_bytes) : 0u;
     if (rows_fast > rows_fit) rows_fast = rows_fit;
     const size_t lds_fast = row_bytes * rows_fast + tail_fixed + 16u;
@@ -1602,12 +1643,10 @@ int ofdmtx_raw_qam_tx(ofdmtx_ctx *ctx, int qambits, int nc, int np, uint32_t nca
     const unsigned grid_fast = (unsigned)(iters_fast < cap ? iters_fast : cap);
 #define LAUNCH_QAM(QB_, NC_, NP_)                                                                         \
     do {                                                                                                  \
-        if (fast_ok && grouped)                                                                           \
-            hipLaunchKernelGGL((k_raw_qam_tx_fast<QB_, NC_, NP_, true>), dim3(grid_fast), dim3(threads),  \
-                               lds_fast, st, Q, d_bytes, o2, in_stride, cod_stride, pun_stride,           \
-                               rows_fast);                                                                \
-        else if (fast_ok)                                                                                 \
-            hipLaunchKernelGGL((k_raw_qam_tx_fast<QB_, NC_, NP_, false>), dim3(grid_fast), dim3(threads), \
+        if (wave_ok && launch_qam_wave<QB_, NC_, NP_>(ctx, Q, d_bytes, o2, st))                           \
+            break;                                                                                        \
+        if (fast_ok)                                                                                      \
+            hipLaunchKernelGGL((k_raw_qam_tx_fast<QB_, NC_, NP_>), dim3(grid_fast), dim3(threads),        \
                                lds_fast, st, Q, d_bytes, o2, in_stride, cod_stride, pun_stride,           \
                                rows_fast);                                                                \
         else                                                                                              \

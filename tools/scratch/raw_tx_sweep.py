@@ -58,8 +58,10 @@ def main():
             same = bool(torch.equal(iq.view(torch.float32), want.view(torch.float32)))
             ms = timed(lambda: mod.modulate_bytes(bitrate, data, nsym, out=iq))
             ms_mod = timed(lambda: plan.modulate(vals, out=want))
+            ms_qam = timed(lambda: tx.modulate(data, out=vals))
             print(json.dumps({"N": nfft, "bitrate": bitrate, "fused": bool(mod.fused), "same": same, "ms": round(ms, 4),
-                              "frac": round(alg / (ms * 1e-3) / 8e12, 4), "modulator_ms": round(ms_mod, 4),
+                              "frac": round(alg / (ms * 1e-3) / 8e12, 4), "modulator_ms": round(ms_mod, 4), "qam_ms": round(ms_qam, 4),
+                              "qam_frac": round((data.numel() + vals.numel() * 8) / (ms_qam * 1e-3) / 8e12, 4),
                               "modulator_frac": round((vals.numel() + plan.n_samples) * 8 / (ms_mod * 1e-3) / 8e12, 4)}), flush=True)
             if not same:
                 return 1
