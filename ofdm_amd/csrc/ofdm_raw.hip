@@ -148,9 +148,11 @@ __device__ __forceinline__ void raw_transform_store(bool active, int t, int lane
         //   bin k = a + A b + 64 c, sample n = V V n1 + V n2 + n3,
         //   x[n] = sum_a W_A^{a n1} W_N^{a (V n2 + n3)} sum_b W_V^{b n2} W_N^{A b n3} sum_c W_V^{c n3} X[k]
         // three in-register transforms of V, V and A points with an exchange through LDS after each
-        // (areas of V x (64 + A), A x (V V + pad) and N values, one after the other in the same
-        // memory); the lane is (a, b) in the first, (a, n3) in the second and (n2, n3) in the third.
-        constexpr int V = M, A = 64 / V, E1 = 64 + A, Q = V * V, E2 = Q + (V == 16 ? 16 : 8);
+        // (areas of V x (64 + 32 / V), A x (V V + pad) and N values, one after the other in the same
+        // memory; the paddings make every exchange free of bank conflicts: 8-byte reads are banked
+        // over 256 bytes per 32 lanes, 8-byte writes over 128 bytes per 16 lanes); the lane is
+        // (a, b) in the first, (a, n3) in the second and (n2, n3) in the third.
+        constexpr int V = M, A = 64 / V, E1 = 64 + 32 / V, Q = V * V, E2 = Q + (V == 16 ? 16 : 8);
         static_assert(V == 8 || V == 16, "64 lanes per symbol: N = 512 or 1024");
         static_assert(V * E1 <= TS && A * E2 <= TS && N <= TS, "symbol area too small");
         idft_reg<V>(x);
@@ -713,12 +715,16 @@ struct GroupLut {
         }
     }
 
-    // where carrier c of a symbol (c = B G + c') sits in the symbol's index row
+    // where carrier c of a symbol (c = B G + c') sits in the symbol's index row; byte kk of word (s, h) of
+    // group c' is the carrier at B = 8 h + 2 kk + s.  PLANAR: the row is four planes (one per word (s, h))
+    // of G dwords, so that neighbouring lanes write, and later read, neighbouring dwords (no bank
+    // conflicts); else the four words of a group lie together (one 16-byte store, fewer registers).
+    template <bool PLANAR>
     static __device__ __forceinline__ uint32_t offset_of(uint32_t c, uint32_t G)
     {
         if constexpr (USED) {
-            const uint32_t B = c / G, cp = c - B * G;
-            return 16u * cp + 4u * (2u * (B & 1u) + (B >> 3)) + ((B >> 1) & 3u);
+            const uint32_t B = c / G, cp = c - B * G, w = 2u * (B & 1u) + (B >> 3), kk = (B >> 1) & 3u;
+            return PLANAR ? 4u * (w * G + cp) + kk : 16u * cp + 4u * w + kk;
         } else {
             return c;
         }
@@ -957,10 +963,11 @@ __device__ __forceinline__ void fused_lut_fill(v2f *s_lut, float scale, int tid,
 
 // byte offset, inside a symbol's index row, of the byte that selects the value of bin code `code`
 // (s_src: >= 0 data carrier, -1 zero, -2 pilot +1, -3 pilot -1)
-template <int QB, int NC, int NP>
+template <int QB, int NC, int NP, bool PLANAR>
 __device__ __forceinline__ uint32_t fused_idx_offset(int code, uint32_t ncarriers)
 {
-    return code >= 0 ? GroupLut<QB, NC, NP>::offset_of((uint32_t)code, ncarriers / 16u) : ncarriers + (uint32_t)(-1 - code);
+    return code >= 0 ? GroupLut<QB, NC, NP>::template offset_of<PLANAR>((uint32_t)code, ncarriers / 16u)
+                     : ncarriers + (uint32_t)(-1 - code);
 }
 
 // the three fixed slots behind a row's index bytes
@@ -1032,6 +1039,10 @@ k_raw_tx(RawParams R, QamTxParams Q, const uint8_t *__restrict__ data, float2 *_
          uint32_t wave_bytes)
 {
     constexpr int N = L * M, S = L > M ? L : M, SPW = 64 / S, TS = raw_area<L, M>();
+    // layout of the index rows: planar from N = 256 on (2-4 % faster; not for BPSK, whose single unit
+    // per group makes the four stores cost more than the reads gain); the small sizes run four
+    // workgroups to a CU and have no registers to spare for it
+    constexpr bool PLANAR = N >= 256 && QB > 1;
     using Units = UnitBits<QB, NC, NP>;
     using GLut = GroupLut<QB, NC, NP>;
     extern __shared__ __align__(16) unsigned char s_raw[];
@@ -1065,7 +1076,7 @@ k_raw_tx(RawParams R, QamTxParams Q, const uint8_t *__restrict__ data, float2 *_
     // where the index byte of each of the lane's M bins sits in a symbol's row: the same for every symbol
     uint32_t ioff[M];
 #pragma unroll
-    for (int m = 0; m < M; m++) ioff[m] = fused_idx_offset<QB, NC, NP>(t < L ? s_src[t + L * m] : -1, Q.ncarriers);
+    for (int m = 0; m < M; m++) ioff[m] = fused_idx_offset<QB, NC, NP, PLANAR>(t < L ? s_src[t + L * m] : -1, Q.ncarriers);
     // the lane's groups of a pass: (row, c') of item lane + 64 it -- the same in every pass
     const SmallDiv gdiv(G), fdiv(R.frame_size);                   // (R.frame_size == Q.nsymbols)
     uint32_t g_row[FUSED_IT], g_c[FUSED_IT];
@@ -1108,7 +1119,13 @@ k_raw_tx(RawParams R, QamTxParams Q, const uint8_t *__restrict__ data, float2 *_
                 if constexpr (GLut::USED) {
                     uint32_t out[4];
                     GLut::emit(ub, s_glut, out);
-                    *reinterpret_cast<uint4 *>(irow + 16u * g_c[it]) = make_uint4(out[0], out[1], out[2], out[3]);
+                    if constexpr (PLANAR) {
+                        uint32_t *plane = reinterpret_cast<uint32_t *>(irow) + g_c[it];
+#pragma unroll
+                        for (int w = 0; w < 4; w++) plane[(uint32_t)w * G] = out[w];
+                    } else {
+                        *reinterpret_cast<uint4 *>(irow + 16u * g_c[it]) = make_uint4(out[0], out[1], out[2], out[3]);
+                    }
                 } else {
                     emit_unit_group<QB, NC, NP, (QB / 2 > 1 ? QB / 2 : 1)>(ub, irow + g_c[it], G, std::make_integer_sequence<int, 16>{});
                 }
