@@ -251,6 +251,9 @@ def main():
     ap.add_argument("--raw-n", type=int, default=256)
     ap.add_argument("--raw-cp", type=int, default=64)
     ap.add_argument("--raw-symbols", type=int, default=1 << 20, help="data symbols per GPU per step (rawofdm)")
+    ap.add_argument("--placement", choices=["probe", "first"], default="probe",
+                    help="output buffer: fastest of a few candidate allocations, or the first allocation as it comes")
+    ap.add_argument("--placement-candidates", type=int, default=5)
     ap.add_argument("--gather", type=int, default=0,
                     help="1: every step also collects all shards' IQ on rank 0 (config 5: RCCL send/recv, chunk k in "
                          "flight under the kernels of chunk k + 1); --packets is cut so that N shards fit the root")
@@ -297,7 +300,20 @@ def main():
     gen.manual_seed(2 + rank)
     payloads = torch.randint(0, 256, (n * PAYLOAD,), dtype=torch.uint8, device=dev, generator=gen)
     msg = plan.alloc_msg() if not gather else None
-    iq = plan.alloc_iq() if not gather else None
+    # the output buffer: where in HBM it lies changes the store rate by up to 10 % on MI355X, so by
+    # default the fastest of a few candidate placements is kept (TxPlan.alloc_iq_probed; --placement
+    # first takes the first allocation as it comes); the candidates' times are part of the JSON line
+    iq, placement = None, None
+    if not gather:
+        if a.placement == "probe":
+            iq, cand_ms = plan.alloc_iq_probed(lambda b: plan.tx(payloads, out=b, work=msg), max_candidates=a.placement_candidates)
+            placement = {"mode": "probe", "candidates_ms": [round(t, 3) for t in cand_ms],
+                         "chosen": int(np.argmin(cand_ms)),
+                         "note": "k_tx timed once into each candidate buffer (allocation order); the fastest is "
+                                 "kept, the others freed before the timed region"}
+        else:
+            iq = plan.alloc_iq()
+            placement = {"mode": "first"}
     if gather:
         from ofdm_amd.dist import chunk_bounds, gather_chunked
         spans = chunk_bounds(n, a.gather_chunks)
@@ -395,7 +411,12 @@ def main():
                        "packets_per_gpu": n, "samples_per_packet": info.n_rows * 80,
                        "parallelism": "packets sharded by index over %d GPU(s), %s" % (
                            world, "IQ gathered on rank 0 every step in %d overlapped chunks" % len(spans) if gather else "no collective")},
+            "iq_placement": placement,
             "kernel_ms": kernels,
+            # spread of the dominant kernel over the timed steps (first, fastest, slowest)
+            "kernel_ms_steps": {"first": float(evs[0][0].elapsed_time(evs[0][1])),
+                                "min": float(min(e[0].elapsed_time(e[1]) for e in evs)),
+                                "max": float(max(e[0].elapsed_time(e[1]) for e in evs))},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": load_traffic("%s_54M_1500B_%dpk" % (kernel, n)),
