@@ -112,6 +112,64 @@ def load_traffic(workload_key):
         return None
 
 
+def alloc_output(ctx, n_samples, mode, fill, candidates=5):
+    """The output buffer of a workload and a record of how it was placed.  Where a large buffer lies in
+    HBM changes the store rate on MI355X (one of the memory's three parts: 5.6-5.7 TB/s, pieces
+    alternating between the parts: 7.1 TB/s), so by default the buffer comes from
+    TxContext.alloc_spread; one launch into an ordinary first allocation is timed beside it for the
+    record.  mode "probe": the fastest of a few ordinary allocations; "first": the first allocation
+    as it comes.  fill(buffer) is the workload's own launch."""
+    dev = ctx.device
+
+    def once(b):
+        fill(b)
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0.record()
+        fill(b)
+        t1.record()
+        t1.synchronize()
+        return float(t0.elapsed_time(t1))
+
+    if mode == "spread":
+        t_alloc = time.perf_counter()
+        raw, spread = ctx.alloc_spread(n_samples * 8)
+        t_alloc = time.perf_counter() - t_alloc
+        iq = raw.view(torch.complex64)
+        if spread:
+            rec = {"mode": "spread", "note": "64 MiB pieces alternating between the three parts of the device memory "
+                                             "(ofdmtx_stream_alloc); one launch timed into it and into an ordinary first "
+                                             "allocation, which is freed before the timed region",
+                   "alloc_s": round(t_alloc, 2), "spread_ms": round(once(iq), 3)}
+            plain = torch.empty(n_samples, dtype=torch.complex64, device=dev)
+            rec["first_allocation_ms"] = round(once(plain), 3)
+            if rec["first_allocation_ms"] < rec["spread_ms"]:
+                iq, rec["kept"] = plain, "first allocation"
+            else:
+                del plain
+                rec["kept"] = "spread"
+            torch.cuda.empty_cache()
+            return iq, rec
+        del iq, raw
+        mode = "probe"                                    # the device could not provide the layout
+    if mode == "probe":
+        cands, times = [], []
+        need = n_samples * 8
+        while len(cands) < max(1, candidates):
+            free, _ = torch.cuda.mem_get_info(dev)
+            if cands and free < need + (8 << 30):
+                break
+            cands.append(torch.empty(n_samples, dtype=torch.complex64, device=dev))
+        times = [once(b) for b in cands]
+        keep = int(np.argmin(times))
+        iq = cands[keep]
+        del cands
+        torch.cuda.empty_cache()
+        return iq, {"mode": "probe", "candidates_ms": [round(t, 3) for t in times], "chosen": keep,
+                    "note": "one launch timed into each candidate buffer (allocation order); the fastest is kept, "
+                            "the others freed before the timed region"}
+    return torch.empty(n_samples, dtype=torch.complex64, device=dev), {"mode": "first"}
+
+
 def timed_steps(step, a, dist, backend, dev):
     """W untimed steps, then K timed ones between barriers; returns (seconds, max over ranks; events)."""
     for _ in range(a.warmup):
@@ -152,7 +210,7 @@ def run_rawofdm(a, ctx, dev, world, rank, dist, backend):
     gen.manual_seed(4 + rank)
     ph = torch.randint(0, 4, (n_frames * size * p.data_tones,), device=dev, generator=gen)
     data = torch.polar(torch.ones_like(ph, dtype=torch.float32), (2 * ph + 1) * (np.pi / 4)).contiguous()   # unit QPSK
-    iq = torch.empty(plan.n_samples, dtype=torch.complex64, device=dev)
+    iq, placement = alloc_output(ctx, plan.n_samples, a.placement, lambda b: plan.modulate(data, out=b), a.placement_candidates)
 
     def step(events=None):
         if events is not None:
@@ -176,6 +234,7 @@ def run_rawofdm(a, ctx, dev, world, rank, dist, backend):
                                    "+ %d preamble symbols per GPU, unit QPSK values -> IQ"
                                    % (a.raw_n, a.raw_cp, o.occupied_tones, p.data_tones, n_frames, size, plan.n_pre),
                        "parallelism": "frames sharded by index over %d GPU(s), no collective" % world},
+            "iq_placement": placement,
             "kernel_ms": {"k_raw_modulate": kernel_ms},
             "roofline": {"bound": "hbm", "kernel": "k_raw_modulate", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
@@ -202,7 +261,7 @@ def run_ragged(a, ctx, dev, world, rank, dist, backend):
     gen = torch.Generator(device=dev)
     gen.manual_seed(3 + rank)
     payloads = torch.randint(0, 256, (int(lens.sum()),), dtype=torch.uint8, device=dev, generator=gen)
-    iq = plan.alloc_iq()
+    iq, placement = alloc_output(ctx, plan.n_samples, a.placement, lambda b: plan.tx(payloads, out=b), a.placement_candidates)
 
     def step(events=None):
         if events is not None:
@@ -229,6 +288,7 @@ def run_ragged(a, ctx, dev, world, rank, dist, backend):
                                    "full PPDU IQ" % n,
                        "packets_per_gpu": n,
                        "parallelism": "packet ranges per rank over %d GPU(s), pilot counter continued, no collective" % world},
+            "iq_placement": placement,
             "kernel_ms": {"k_tx": kernel_ms},
             "roofline": {"bound": "hbm", "kernel": "k_tx (ragged)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
@@ -251,8 +311,9 @@ def main():
     ap.add_argument("--raw-n", type=int, default=256)
     ap.add_argument("--raw-cp", type=int, default=64)
     ap.add_argument("--raw-symbols", type=int, default=1 << 20, help="data symbols per GPU per step (rawofdm)")
-    ap.add_argument("--placement", choices=["probe", "first"], default="probe",
-                    help="output buffer: fastest of a few candidate allocations, or the first allocation as it comes")
+    ap.add_argument("--placement", choices=["spread", "probe", "first"], default="spread",
+                    help="output buffer: pieces alternating between the parts of the device memory, the fastest of a "
+                         "few ordinary allocations, or the first allocation as it comes")
     ap.add_argument("--placement-candidates", type=int, default=5)
     ap.add_argument("--gather", type=int, default=0,
                     help="1: every step also collects all shards' IQ on rank 0 (config 5: RCCL send/recv, chunk k in "
@@ -300,20 +361,10 @@ def main():
     gen.manual_seed(2 + rank)
     payloads = torch.randint(0, 256, (n * PAYLOAD,), dtype=torch.uint8, device=dev, generator=gen)
     msg = plan.alloc_msg() if not gather else None
-    # the output buffer: where in HBM it lies changes the store rate by up to 10 % on MI355X, so by
-    # default the fastest of a few candidate placements is kept (TxPlan.alloc_iq_probed; --placement
-    # first takes the first allocation as it comes); the candidates' times are part of the JSON line
     iq, placement = None, None
     if not gather:
-        if a.placement == "probe":
-            iq, cand_ms = plan.alloc_iq_probed(lambda b: plan.tx(payloads, out=b, work=msg), max_candidates=a.placement_candidates)
-            placement = {"mode": "probe", "candidates_ms": [round(t, 3) for t in cand_ms],
-                         "chosen": int(np.argmin(cand_ms)),
-                         "note": "k_tx timed once into each candidate buffer (allocation order); the fastest is "
-                                 "kept, the others freed before the timed region"}
-        else:
-            iq = plan.alloc_iq()
-            placement = {"mode": "first"}
+        iq, placement = alloc_output(ctx, plan.n_samples, a.placement, lambda b: plan.tx(payloads, out=b, work=msg),
+                                     a.placement_candidates)
     if gather:
         from ofdm_amd.dist import chunk_bounds, gather_chunked
         spans = chunk_bounds(n, a.gather_chunks)

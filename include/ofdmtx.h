@@ -390,6 +390,19 @@ int ofdmtx_raw_qam_tx(ofdmtx_ctx *ctx, int qambits, int nc, int np, uint32_t nca
 int ofdmtx_raw_tx(ofdmtx_ctx *ctx, const ofdmtx_raw_plan *plan, int qambits, int nc, int np,
                   const uint8_t *d_bytes, float *d_iq, void *stream);
 
+/* ---- placement of a large, long-lived output buffer ----------------------------------------------
+ * No counterpart in the reference (its sinks own their buffers).  On MI355X streaming stores into a
+ * buffer that lies in one of the memory's three 96 GiB parts run at 5.6-5.7 TB/s, into a buffer
+ * whose pieces alternate between the parts at 7.1 TB/s.  ofdmtx_stream_alloc returns `bytes` of
+ * device memory made of 64 MiB pieces taken in turn from three far-apart places of the device
+ * (HIP virtual-memory API; for the duration of the call it takes nearly all free memory of the
+ * device as such pieces and gives the unused ones back), usable like any device pointer for d_iq.
+ * *spread (may be NULL) tells whether that worked; with less than three quarters of the device
+ * free, or on any failure on the way, the buffer is an ordinary hipMalloc allocation and *spread is
+ * 0.  ofdmtx_stream_free releases either kind (after a device synchronisation). */
+int ofdmtx_stream_alloc(ofdmtx_ctx *ctx, uint64_t bytes, void **out, int *spread);
+int ofdmtx_stream_free(ofdmtx_ctx *ctx, void *ptr);
+
 /* ---- optional exchange: the ranks' IQ shards into one buffer on a root GPU -----------------------
  * Packets are sharded over GPUs by index and nothing on the transmit path needs another rank's
  * data; this is for a consumer that wants ONE stream, as the reference's flowgraph ends in one sink

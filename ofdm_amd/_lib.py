@@ -84,6 +84,8 @@ PROTOTYPES = {
     "ofdmtx_raw_plan_get_sizes": (C.c_int, [_VP, C.POINTER(RawSizes)]),
     "ofdmtx_raw_modulate": (C.c_int, [_VP] * 6),
     "ofdmtx_raw_taps": (C.c_int, [_VP] * 8),
+    "ofdmtx_stream_alloc": (C.c_int, [_VP, C.c_uint64, C.POINTER(_VP), C.POINTER(C.c_int)]),
+    "ofdmtx_stream_free": (C.c_int, [_VP, _VP]),
     "ofdmtx_comm_unique_id": (C.c_int, [_VP]),
     "ofdmtx_comm_create": (C.c_int, [_VP, C.c_int, C.c_int, _VP, C.POINTER(_VP)]),
     "ofdmtx_comm_destroy": (C.c_int, [_VP]),

@@ -32,6 +32,27 @@ def _check_buffer(name, t, dtype, device, numel):
     return t
 
 
+class _StreamMemory(object):
+    """Device memory from ofdmtx_stream_alloc, presented to torch through the CUDA array interface;
+    released when the last tensor that views it is gone."""
+
+    def __init__(self, ctx, n_bytes):
+        self._lib, self._ctx_h, self._ctx = ctx._lib, ctx._h, ctx          # (keeps the context alive)
+        ptr, spread = C.c_void_p(), C.c_int()
+        _lib.check(self._lib.ofdmtx_stream_alloc(ctx._h, int(n_bytes), C.byref(ptr), C.byref(spread)))
+        self.ptr, self.n_bytes, self.spread = ptr.value, int(n_bytes), bool(spread.value)
+        self.__cuda_array_interface__ = {"shape": (self.n_bytes,), "typestr": "|u1", "data": (self.ptr, False),
+                                         "version": 2, "strides": None}
+
+    def __del__(self):
+        try:
+            if getattr(self, "ptr", None):
+                self._lib.ofdmtx_stream_free(self._ctx_h, C.c_void_p(self.ptr))
+                self.ptr = None
+        except Exception:
+            pass
+
+
 class TxContext:
     """One per GPU: owns the device-side tables (scrambler words, constellations, preamble,
     twiddles)."""
@@ -55,6 +76,15 @@ class TxContext:
             self.close()
         except Exception:
             pass
+
+    def alloc_spread(self, n_bytes):
+        """n_bytes of device memory (uint8 tensor) whose 64 MiB pieces alternate between the parts of
+        the device memory (ofdmtx_stream_alloc): streaming stores into it run at up to 7.1 instead of
+        5.7 TB/s on MI355X.  Meant for long-lived output buffers: the call takes most of the device's
+        free memory for a moment (seconds).  Returns (tensor, spread) -- spread False: the device
+        could not provide the layout and the buffer is an ordinary allocation."""
+        mem = _StreamMemory(self, int(n_bytes))
+        return torch.as_tensor(mem, device=self.device), mem.spread
 
     def set_constellation(self, n_bpsc, points):
         """`constellation` argument of ftw.ofdm_mapper for DATA symbols with n_bpsc bits/carrier."""
@@ -211,6 +241,11 @@ class TxPlan:
 
     def alloc_iq(self):
         return torch.empty(self.n_samples, dtype=torch.complex64, device=self.ctx.device)
+
+    def alloc_iq_spread(self):
+        """The plan's output buffer from TxContext.alloc_spread: (complex64 tensor, spread)."""
+        t, spread = self.ctx.alloc_spread(self.n_samples * 8)
+        return t.view(torch.complex64), spread
 
     def alloc_iq_probed(self, fill, max_candidates=5, reserve_bytes=8 << 30, launches=2):
         """An output buffer for a long-lived, repeatedly written stream, placed where the device writes

@@ -37,6 +37,9 @@ def test_headline_line():
     assert d["map_ifft_cp_only"]["bytes_per_packet"] == 2058 + 58 * 640 and d["map_ifft_cp_only"]["ms"] > 0
     # the fused kernel and the two-kernel path were both run
     assert d["kernel_ms"]["k_tx"] > 0 and d["two_kernel_path"]["k_tx_msg_ms"] > 0
+    # how the output buffer was placed is part of the line, with the ordinary allocation's time beside it
+    pl = d["iq_placement"]
+    assert pl["mode"] in ("spread", "probe") and (pl["mode"] != "spread" or pl["first_allocation_ms"] > 0)
 
 
 @pytest.mark.gpu
@@ -44,8 +47,8 @@ def test_headline_line():
                                   ("--workload", "rawofdm", "--raw-n", "1024", "--raw-cp", "128", "--raw-symbols", "4096"),
                                   ("--workload", "ragged", "--ragged-packets", "3000")], ids=["raw256", "raw1024", "ragged"])
 def test_secondary_lines(args):
-    d = run_bench(*args)
-    assert KEYS <= set(d) and ROOF <= set(d["roofline"])
+    d = run_bench("--placement", "probe", *args)
+    assert KEYS <= set(d) and ROOF <= set(d["roofline"]) and d["iq_placement"]["mode"] == "probe"
     assert d["value"] > 0 and 0 < d["roofline"]["frac"] < 1 and "workload" in d["config"]
 
 

@@ -305,3 +305,36 @@ def test_probed_output_placement_keeps_one_buffer(txctx):
     assert torch.equal(iq.view(torch.float32), want.view(torch.float32))
     free1, _ = torch.cuda.mem_get_info(txctx.device)
     assert free0 - free1 <= plan.n_samples * 8 + (64 << 20)          # one buffer kept (allocator rounding aside)
+
+
+def test_spread_output_buffer(txctx):
+    """ofdmtx_stream_alloc / ofdmtx_stream_free through TxContext.alloc_spread: the buffer is usable as
+    d_iq like any device memory (same samples as into an ordinary allocation, device-to-host copy
+    included), its memory returns to the device when the last tensor viewing it is gone, and a pointer
+    the library did not hand out is refused."""
+    plan = txctx.plan_uniform(3000, 8, 1500)
+    pay = torch.randint(0, 256, (plan.payload_bytes,), dtype=torch.uint8, device=txctx.device)
+    want = plan.tx(pay)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free0, total = torch.cuda.mem_get_info(txctx.device)
+    iq, spread = plan.alloc_iq_spread()
+    assert iq.dtype == torch.complex64 and iq.numel() == plan.n_samples and iq.device == txctx.device
+    if free0 > 0.8 * total:
+        assert spread, "a nearly empty device must provide the layout"
+    iq.zero_()
+    plan.tx(pay, out=iq)
+    torch.cuda.synchronize()
+    assert torch.equal(iq.view(torch.float32), want.view(torch.float32))
+    assert np.array_equal(iq[:4096].cpu().numpy(), want[:4096].cpu().numpy())
+    part = iq[100:200]                                               # a view keeps the memory alive
+    del iq
+    assert torch.equal(part, want[100:200])
+    del part
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info(txctx.device)
+    assert free0 - free1 < (256 << 20), "the buffer's memory did not return to the device"
+    lib = txctx._lib
+    assert lib.ofdmtx_stream_free(txctx._h, C.c_void_p(want.data_ptr())) == _lib.EINVAL
+    ptr = C.c_void_p()
+    assert lib.ofdmtx_stream_alloc(txctx._h, 0, C.byref(ptr), None) == _lib.EINVAL

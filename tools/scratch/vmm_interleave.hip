@@ -1,0 +1,77 @@
+// Micro-benchmark: if stores into two of the memory's three 96 GiB parts at once are faster than into one, what
+// about an output buffer whose consecutive pieces ALTERNATE between the parts?  The device memory is taken in
+// physical handles of CHUNK MiB through the virtual-memory API (in the order the driver hands them out, assumed -- and
+// checked by the result -- to be ascending), and three 48 GB buffers are mapped from them:
+//   one part    consecutive handles of the first part
+//   two parts   pieces alternately from the first and the second part
+//   three parts pieces from the three parts in turn
+// then the wave-per-packet store pattern (48 000-byte packets, no reads) is timed into each.
+// usage: vmm_interleave <chunk MiB>
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("hip error %d (%s) at %d\n", (int)e, hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+__global__ void __launch_bounds__(512) k_pkt(float4 *__restrict__ out, uint32_t n_pkts)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t step = gridDim.x * 8;
+    for (uint32_t p = blockIdx.x * 8 + wave; p < n_pkts; p += step) {
+        float4 *dst = out + (size_t)p * 3000;
+        for (int i = lane; i < 3000; i += 64) dst[i] = make_float4(1.f, 2.f, 3.f, (float)i);
+    }
+}
+
+int main(int argc, char **argv)
+{
+    const size_t MiB = 1ull << 20, GiB = 1ull << 30;
+    const size_t chunk = (size_t)atoi(argv[1]) * MiB;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = 0;
+    size_t gran = 0;
+    CK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+    printf("granularity %zu, chunk %zu MiB\n", gran, chunk / MiB);
+    size_t free_b, total_b;
+    CK(hipMemGetInfo(&free_b, &total_b));
+    const size_t n_handles = (free_b - 6 * GiB) / chunk;
+    std::vector<hipMemGenericAllocationHandle_t> h(n_handles);
+    for (size_t k = 0; k < n_handles; k++) CK(hipMemCreate(&h[k], chunk, &prop, 0));
+    printf("%zu handles = %.1f GiB\n", n_handles, n_handles * chunk / (double)GiB);
+    const size_t per_part = 96 * GiB / chunk;                 // handles per 96 GiB
+    const uint32_t n = 1000000;
+    const size_t pieces = ((size_t)n * 48000 + chunk - 1) / chunk;
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    const char *names[3] = {"one part", "two parts alternating", "three parts in turn"};
+    void *bufs[3];
+    size_t used[3] = {per_part / 8, per_part / 8, per_part / 8};   // next free handle of each part (skip the first 12 GiB)
+    for (int b = 0; b < 3; b++) {
+        CK(hipMemAddressReserve(&bufs[b], pieces * chunk, chunk, nullptr, 0));
+        for (size_t i = 0; i < pieces; i++) {
+            const int part = b == 0 ? 0 : (int)(i % (b + 1));
+            const size_t k = part * per_part + used[part]++;
+            if (k >= n_handles || (part < 2 && used[part] > per_part)) { printf("out of handles in part %d\n", part); return 1; }
+            CK(hipMemMap((char *)bufs[b] + i * chunk, chunk, 0, h[k], 0));
+        }
+        CK(hipMemSetAccess(bufs[b], pieces * chunk, &acc, 1));
+    }
+    hipEvent_t ev0, ev1;
+    CK(hipEventCreate(&ev0)); CK(hipEventCreate(&ev1));
+    for (int rep = 0; rep < 2; rep++)
+        for (int b = 0; b < 3; b++) {
+            hipLaunchKernelGGL(k_pkt, dim3(512), dim3(512), 0, 0, (float4 *)bufs[b], n);
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(ev0));
+            for (int r = 0; r < 3; r++) hipLaunchKernelGGL(k_pkt, dim3(512), dim3(512), 0, 0, (float4 *)bufs[b], n);
+            CK(hipEventRecord(ev1));
+            CK(hipEventSynchronize(ev1));
+            float ms; CK(hipEventElapsedTime(&ms, ev0, ev1));
+            printf("%-24s %.3f ms %.2f TB/s\n", names[b], ms / 3, 48e9 / (ms / 3) / 1e9);
+            fflush(stdout);
+        }
+    return 0;
+}
