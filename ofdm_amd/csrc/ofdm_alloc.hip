@@ -5,8 +5,8 @@
 // out of 64 MiB pieces of physical memory taken in turn from three far-apart places, mapped back to
 // back into one range of addresses (HIP's virtual-memory API), so that whatever is being written at
 // one moment -- a few hundred MB of neighbouring packets -- is spread over the parts.  (Two parts
-// give the same rate for stores alone; with the payload reads beside them three are better: k_tx
-// 8.33 against 8.45 ms.)
+// give the same rate for stores alone, and keeping the inputs in the remaining part buys k_tx
+// nothing: 8.32-8.39 ms in every combination.)
 //
 // Where a piece of physical memory lies is not visible to a user process.  What can be relied on
 // (measured, not documented): the driver hands out pieces of one size in ascending order.  So the
