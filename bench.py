@@ -112,7 +112,7 @@ def load_traffic(workload_key):
         return None
 
 
-def alloc_output(ctx, n_samples, mode, fill, candidates=5):
+def alloc_output(ctx, n_samples, mode, fill, candidates=5, compare=True):
     """The output buffer of a workload and a record of how it was placed.  Where a large buffer lies in
     HBM changes the store rate on MI355X (one of the memory's three parts: 5.6-5.7 TB/s, pieces
     alternating between the parts: 7.1 TB/s), so by default the buffer comes from
@@ -137,17 +137,17 @@ def alloc_output(ctx, n_samples, mode, fill, candidates=5):
         iq = raw.view(torch.complex64)
         if spread:
             rec = {"mode": "spread", "note": "64 MiB pieces alternating between the three parts of the device memory "
-                                             "(ofdmtx_stream_alloc); one launch timed into it and into an ordinary first "
-                                             "allocation, which is freed before the timed region",
+                                             "(ofdmtx_stream_alloc); one launch timed into it and (unless --placement-compare "
+                                             "0) into an ordinary first allocation, which is freed before the timed region",
                    "alloc_s": round(t_alloc, 2), "spread_ms": round(once(iq), 3)}
-            plain = torch.empty(n_samples, dtype=torch.complex64, device=dev)
-            rec["first_allocation_ms"] = round(once(plain), 3)
-            if rec["first_allocation_ms"] < rec["spread_ms"]:
-                iq, rec["kept"] = plain, "first allocation"
-            else:
+            rec["kept"] = "spread"
+            if compare:
+                plain = torch.empty(n_samples, dtype=torch.complex64, device=dev)
+                rec["first_allocation_ms"] = round(once(plain), 3)
+                if rec["first_allocation_ms"] < rec["spread_ms"]:
+                    iq, rec["kept"] = plain, "first allocation"
                 del plain
-                rec["kept"] = "spread"
-            torch.cuda.empty_cache()
+                torch.cuda.empty_cache()
             return iq, rec
         del iq, raw
         mode = "probe"                                    # the device could not provide the layout
@@ -210,7 +210,7 @@ def run_rawofdm(a, ctx, dev, world, rank, dist, backend):
     gen.manual_seed(4 + rank)
     ph = torch.randint(0, 4, (n_frames * size * p.data_tones,), device=dev, generator=gen)
     data = torch.polar(torch.ones_like(ph, dtype=torch.float32), (2 * ph + 1) * (np.pi / 4)).contiguous()   # unit QPSK
-    iq, placement = alloc_output(ctx, plan.n_samples, a.placement, lambda b: plan.modulate(data, out=b), a.placement_candidates)
+    iq, placement = alloc_output(ctx, plan.n_samples, a.placement, lambda b: plan.modulate(data, out=b), a.placement_candidates, bool(a.placement_compare))
 
     def step(events=None):
         if events is not None:
@@ -261,7 +261,7 @@ def run_ragged(a, ctx, dev, world, rank, dist, backend):
     gen = torch.Generator(device=dev)
     gen.manual_seed(3 + rank)
     payloads = torch.randint(0, 256, (int(lens.sum()),), dtype=torch.uint8, device=dev, generator=gen)
-    iq, placement = alloc_output(ctx, plan.n_samples, a.placement, lambda b: plan.tx(payloads, out=b), a.placement_candidates)
+    iq, placement = alloc_output(ctx, plan.n_samples, a.placement, lambda b: plan.tx(payloads, out=b), a.placement_candidates, bool(a.placement_compare))
 
     def step(events=None):
         if events is not None:
@@ -315,6 +315,8 @@ def main():
                     help="output buffer: pieces alternating between the parts of the device memory, the fastest of a "
                          "few ordinary allocations, or the first allocation as it comes")
     ap.add_argument("--placement-candidates", type=int, default=5)
+    ap.add_argument("--placement-compare", type=int, default=1,
+                    help="0: no comparison launch into an ordinary allocation (profiler runs: keeps the kernel's average clean)")
     ap.add_argument("--gather", type=int, default=0,
                     help="1: every step also collects all shards' IQ on rank 0 (config 5: RCCL send/recv, chunk k in "
                          "flight under the kernels of chunk k + 1); --packets is cut so that N shards fit the root")
@@ -364,7 +366,7 @@ def main():
     iq, placement = None, None
     if not gather:
         iq, placement = alloc_output(ctx, plan.n_samples, a.placement, lambda b: plan.tx(payloads, out=b, work=msg),
-                                     a.placement_candidates)
+                                     a.placement_candidates, bool(a.placement_compare))
     if gather:
         from ofdm_amd.dist import chunk_bounds, gather_chunked
         spans = chunk_bounds(n, a.gather_chunks)

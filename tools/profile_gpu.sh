@@ -11,9 +11,9 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- \
-    python3 "$R/bench.py" --steps 5 --warmup 2 --cpu-sample 0 "$@" > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.err" || exit 1
+    python3 "$R/bench.py" --steps 20 --warmup 5 --cpu-sample 0 --placement-compare 0 "$@" > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.err" || exit 1
 for CTR in FETCH_SIZE WRITE_SIZE; do
     timeout -s KILL 200 rocprofv3 --pmc $CTR --output-format csv -d "$OUT/pmc_$CTR" -- \
-        python3 "$R/bench.py" --steps 2 --warmup 1 --cpu-sample 0 "$@" > /dev/null 2> "$OUT/pmc_$CTR.err" || exit 1
+        python3 "$R/bench.py" --steps 2 --warmup 1 --cpu-sample 0 --placement-compare 0 "$@" > /dev/null 2> "$OUT/pmc_$CTR.err" || exit 1
 done
 echo "profiles written to $OUT"

@@ -39,6 +39,34 @@ __global__ void __launch_bounds__(512) k_pkt_rd(float4 *__restrict__ out, const 
     }
 }
 
+// the same with the NEXT packet's payload requested before this packet's stores and a counted wait
+// (47 stores may still be outstanding when the loads are needed)
+__global__ void __launch_bounds__(512) k_pkt_ahead(float4 *__restrict__ out, const uint32_t *__restrict__ pay, uint32_t n_pkts)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t stride = gridDim.x * 8;
+    uint32_t r0, r1, r2, r3, r4, r5;
+    uint32_t p = blockIdx.x * 8 + wave;
+#define LOADS(pp) do { const uint32_t *q = pay + (size_t)(pp) * 375 + lane;                                \
+        asm volatile("global_load_dword %0, %1, off" : "=v"(r0) : "v"(q) : "memory");                       \
+        asm volatile("global_load_dword %0, %1, off offset:256" : "=v"(r1) : "v"(q) : "memory");            \
+        asm volatile("global_load_dword %0, %1, off offset:512" : "=v"(r2) : "v"(q) : "memory");            \
+        asm volatile("global_load_dword %0, %1, off offset:768" : "=v"(r3) : "v"(q) : "memory");            \
+        asm volatile("global_load_dword %0, %1, off offset:1024" : "=v"(r4) : "v"(q) : "memory");           \
+        asm volatile("global_load_dword %0, %1, off offset:1280" : "=v"(r5) : "v"(q) : "memory"); } while (0)
+    if (p < n_pkts) LOADS(p);
+    for (; p < n_pkts; p += stride) {
+        asm volatile("s_waitcnt vmcnt(47)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5) :: "memory");
+        const float acc = (float)(r0 ^ r1 ^ r2 ^ r3 ^ r4 ^ r5);
+        { const uint32_t pn = p + stride < n_pkts ? p + stride : p; LOADS(pn); }
+        float4 *dst = out + (size_t)p * 3000;
+#pragma unroll
+        for (int c = 0; c < 46; c++) dst[c * 64 + lane] = make_float4(acc, 2.f, 3.f, (float)c);
+        if (lane < 56) dst[46 * 64 + lane] = make_float4(acc, 2.f, 3.f, 46.f);
+        else asm volatile("" ::: "memory");
+    }
+}
+
 int main(int argc, char **argv)
 {
     const size_t MiB = 1ull << 20, GiB = 1ull << 30;
@@ -95,7 +123,15 @@ int main(int argc, char **argv)
             CK(hipEventRecord(ev1));
             CK(hipEventSynchronize(ev1));
             CK(hipEventElapsedTime(&ms, ev0, ev1));
-            printf(" | with the payload reads %.3f ms\n", ms / 3);
+            printf(" | with the payload reads %.3f ms", ms / 3);
+            hipLaunchKernelGGL(k_pkt_ahead, dim3(512), dim3(512), 0, 0, (float4 *)bufs[b], pay, n);
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(ev0));
+            for (int r = 0; r < 3; r++) hipLaunchKernelGGL(k_pkt_ahead, dim3(512), dim3(512), 0, 0, (float4 *)bufs[b], pay, n);
+            CK(hipEventRecord(ev1));
+            CK(hipEventSynchronize(ev1));
+            CK(hipEventElapsedTime(&ms, ev0, ev1));
+            printf(" | reads one packet ahead %.3f ms\n", ms / 3);
             fflush(stdout);
         }
     return 0;
