@@ -338,3 +338,25 @@ def test_spread_output_buffer(txctx):
     assert lib.ofdmtx_stream_free(txctx._h, C.c_void_p(want.data_ptr())) == _lib.EINVAL
     ptr = C.c_void_p()
     assert lib.ofdmtx_stream_alloc(txctx._h, 0, C.byref(ptr), None) == _lib.EINVAL
+
+
+def test_spread_allocation_falls_back_when_the_device_is_occupied(txctx):
+    """With less than three quarters of the device free the pieces cannot be taken from far-apart places:
+    the call still returns usable memory (an ordinary allocation) and says so; two buffers can be live at once."""
+    torch.cuda.empty_cache()
+    free0, total = torch.cuda.mem_get_info(txctx.device)
+    if free0 < 0.8 * total:
+        pytest.skip("the device is not empty enough to stage this")
+    first, spread1 = txctx.alloc_spread(1 << 30)
+    hog = torch.empty(int(0.5 * total), dtype=torch.uint8, device=txctx.device)       # half of the device
+    second, spread2 = txctx.alloc_spread(1 << 30)
+    assert spread1 and not spread2
+    first.fill_(7)
+    second.fill_(9)
+    torch.cuda.synchronize()
+    assert int(first[-1]) == 7 and int(second[0]) == 9 and int(second[-1]) == 9
+    del first, second, hog
+    torch.cuda.empty_cache()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info(txctx.device)
+    assert free0 - free1 < (256 << 20)
