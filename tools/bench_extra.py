@@ -35,11 +35,24 @@ def timed(fn, steps, warmup=2):
     return float(np.median([a.elapsed_time(b) for a, b in ev]))
 
 
+# Output buffers: one arena of device memory whose 64 MiB pieces alternate between the three parts of the device
+# memory (TxContext.alloc_spread; --placement first: ordinary allocations), carved up per workload.
+ARENA = {"mem": None, "mode": "first"}
+
+
+def out_buffer(ctx, n_samples):
+    need = int(n_samples) * 8
+    if ARENA["mem"] is not None and ARENA["mem"].numel() >= need:
+        return ARENA["mem"][:need].view(torch.complex64)
+    return torch.empty(int(n_samples), dtype=torch.complex64, device=ctx.device)
+
+
 def line(name, ms, alg_bytes, samples, extra):
     gbs = alg_bytes / (ms * 1e-3) / 1e9
     out = {"workload": name, "kernel_ms": ms, "Msamples_per_s": samples / (ms * 1e-3) / 1e6,
            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg_bytes}}
+    out["output_placement"] = ARENA["mode"]
     out.update(extra)
     print(json.dumps(out), flush=True)
 
@@ -50,9 +63,15 @@ def main():
     ap.add_argument("--ragged-packets", type=int, default=400_000)
     ap.add_argument("--raw-symbols", type=int, default=1 << 20)
     ap.add_argument("--only", choices=["qam", "chain"], default=None, help="run one section only")
+    ap.add_argument("--placement", choices=["spread", "first"], default="spread")
+    ap.add_argument("--arena-gb", type=float, default=90.0, help="size of the spread output arena")
     a = ap.parse_args()
     ctx = TxContext(0)
     dev = ctx.device
+    if a.placement == "spread":
+        mem, spread = ctx.alloc_spread(int(a.arena_gb * 1e9) // 8 * 8)
+        if spread:
+            ARENA["mem"], ARENA["mode"] = mem, "spread"
     if a.only == "qam":
         return bench_qam_tx(ctx, a.steps)
     if a.only == "chain":
@@ -65,7 +84,7 @@ def main():
     lens = rng.integers(1, 2305, n).astype(np.uint32)
     payloads = torch.randint(0, 256, (int(lens.sum()),), dtype=torch.uint8, device=dev)
     plan = ctx.plan_ragged(regimes, lens)
-    iq = plan.alloc_iq()
+    iq = out_buffer(ctx, plan.n_samples)
     ms = timed(lambda: plan.tx(payloads, out=iq), a.steps)
     line("mixed-rate ragged batch, payload -> IQ (fused kernel)", ms, int(lens.sum()) + plan.n_samples * 8,
          plan.n_samples, {"packets": n})
@@ -85,7 +104,7 @@ def main():
     lens = rng.integers(0, 101, n).astype(np.uint32)
     payloads = torch.randint(0, 256, (int(lens.sum()),), dtype=torch.uint8, device=dev)
     plan = ctx.plan_ragged(regimes, lens)
-    iq = plan.alloc_iq()
+    iq = out_buffer(ctx, plan.n_samples)
     ms = timed(lambda: plan.tx(payloads, out=iq), a.steps)
     msg = plan.alloc_msg()
     ms_e = timed(lambda: plan.encode_bits(payloads, out=msg), a.steps)
@@ -98,7 +117,7 @@ def main():
         npk = 200_000 if regime == 1 else 500_000
         plan = ctx.plan_uniform(npk, regime, 1500)
         payloads = torch.randint(0, 256, (npk * 1500,), dtype=torch.uint8, device=dev)
-        iq = plan.alloc_iq()
+        iq = out_buffer(ctx, plan.n_samples)
         ms = timed(lambda: plan.tx(payloads, out=iq), a.steps)
         line("regime %d, %d x 1500-byte packets, payload -> IQ (fused kernel)" % (regime, npk), ms,
              npk * 1500 + plan.n_samples * 8, plan.n_samples, {"packets": npk})
@@ -116,7 +135,7 @@ def main():
         plan = raw.plan_frames(ctx, p.fft_length, p.cp_length, p.padded_carriers, p.padded_preambles, n_frames, 16)
         ph = torch.randint(0, 4, (n_frames * 16 * p.data_tones,), device=dev)
         data = torch.polar(torch.ones_like(ph, dtype=torch.float32), (2 * ph + 1) * (np.pi / 4)).contiguous()
-        iq = torch.empty(plan.n_samples, dtype=torch.complex64, device=dev)
+        iq = out_buffer(ctx, plan.n_samples)
         ms = timed(lambda: plan.modulate(data, out=iq), a.steps)
         line("variable-size modulator N=%d cp=%d, %d data symbols in frames of 16 (+3 preamble rows)"
              % (nfft, cp, n_frames * 16), ms, data.numel() * 8 + plan.n_samples * 8, plan.n_samples,
@@ -133,7 +152,7 @@ def bench_qam_tx(ctx, steps):
         tx = raw.qam_tx(bitrate, ncar, 16, ctx=ctx)
         n_frames = (1 << 20) // 16 if ncar == 192 else (1 << 18) // 16
         data = torch.randint(0, 256, (n_frames * tx.framebytes,), dtype=torch.uint8, device=dev)
-        out = torch.empty(n_frames * 16 * ncar, dtype=torch.complex64, device=dev)
+        out = out_buffer(ctx, n_frames * 16 * ncar)
         ms = timed(lambda: tx.modulate(data, out=out), steps)
         line("rawofdm qam_tx bitrate %d, %d carriers x 16 symbols per frame, %d frames" % (bitrate, ncar, n_frames),
              ms, data.numel() + out.numel() * 8, out.numel(), {"frames": n_frames})
@@ -155,7 +174,7 @@ def bench_raw_chain(ctx, steps):
         tx = raw.qam_tx(bitrate, p.data_tones, nsym, ctx=ctx)
         data = torch.randint(0, 256, (n_frames * tx.framebytes,), dtype=torch.uint8, device=dev)
         plan = raw.plan_frames(ctx, p.fft_length, p.cp_length, p.padded_carriers, p.padded_preambles, n_frames, nsym)
-        iq = torch.empty(plan.n_samples, dtype=torch.complex64, device=dev)
+        iq = out_buffer(ctx, plan.n_samples)
         vals = torch.empty(n_frames * nsym * p.data_tones, dtype=torch.complex64, device=dev)
 
         def two():
