@@ -110,7 +110,8 @@ __device__ __forceinline__ void idft8(v2f (&x)[8])
 
 // IQ stores.  A wave addresses a run of output rows through a buffer resource (base in
 // SGPRs, 32-bit byte offsets per lane), which is also the way to give the stores a cache policy the
-// compiler knows about: IQ_STORE_AUX is the instruction's policy field, 16 = sc1.  The samples are
+// compiler knows about: IQ_STORE_AUX is the instruction's policy field (1 = sc0, 2 = nt, 16 = sc1;
+// a translation unit may set it before including this file).  The samples are
 // written once and never read back by this kernel; with sc1 the payload reads issued beside them
 // cost measurably less (48 GB of such stores next to 1.5 GB of reads: 9.60 against 9.75 ms), the
 // stores themselves run at the same rate.

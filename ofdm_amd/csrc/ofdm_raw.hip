@@ -111,10 +111,16 @@ constexpr int bit_reverse(int i, int n)
 }
 
 constexpr int RAW_WAVES = 4;
-// Store policy of the modulator's output rows: plain.  These kernels read 0.6 bytes per byte written (the
-// 802.11a kernel 0.03), and with sc1 on the stores they are slower, not faster (N=256: 1.00 against 0.97 ms,
-// N=1024: 1.07 against 0.97 ms per 1.05e6 / 2.6e5 symbols); the bit chain's value stores keep sc1 (2-3 % faster).
-constexpr int RAW_ROW_AUX = 0;
+// Store policy of these kernels' output (the policy field of the buffer store: 1 = sc0, 2 = nt,
+// 16 = sc1): non-temporal for the modulator's rows and for the bit chain's values.  They read 0.6
+// bytes per byte written (the 802.11a kernel 0.03), and what suits them changed with where the
+// output lies: into an ordinary allocation (one part of the device memory) plain stores were best
+// for the rows (sc1: N=1024 1.07 against 0.97 ms); into a buffer spread over the parts -- variants
+// interleaved in one process -- nt gives bytes -> IQ 0.61 -> 0.53 ms at N=256 and 0.78 -> 0.63 ms at
+// N=1024, the modulator alone 1-2 %, the bit chain's values 0.293 -> 0.249 ms (nt + sc1 is worse than
+// nt for the rows, the same for the values; non-temporal LOADS of the carrier values cost 25 %;
+// raised wave priority for the store phase: nothing).
+constexpr int RAW_ROW_AUX = 2, RAW_VAL_AUX = 2;
 
 // float2 per symbol area: the padded transposition layout M x (L + 1), which also holds the N
 // time-domain samples afterwards (the cyclic prefix is not staged: it is read from the tail again)
@@ -1225,7 +1231,7 @@ k_raw_qam_wave(QamTxParams Q, const uint8_t *__restrict__ data, float2 *__restri
         for (uint32_t i = lane; i < n_pairs; i += 64u) {
             const uint32_t v = *reinterpret_cast<const uint16_t *>(idx_wave + 2u * i);
             const v2f a = s_lut[v & 0xFFu], b = s_lut[v >> 8];
-            iq_store(win, i, make_float4(a.x, a.y, b.x, b.y));
+            iq_store<RAW_VAL_AUX>(win, i, make_float4(a.x, a.y, b.x, b.y));
         }
     }
 }

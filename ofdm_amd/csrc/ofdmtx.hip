@@ -23,6 +23,10 @@
 #include <utility>
 #include <vector>
 
+// Cache policy of this file's IQ stores: non-temporal + sc1 (18).  Against sc1 alone, which the other
+// translation units keep: 7.79 against 7.93 ms per 10^6 packets into a spread output buffer, 8.27
+// against 8.52 ms into an ordinary one (variants interleaved in one process).
+#define IQ_STORE_AUX 18
 #include "ofdm_common.h"
 #include "ofdm_plan.h"
 #include "ofdm_tables.h"
@@ -1020,6 +1024,12 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ in, float2 *__restri
             const uint32_t slot_word0 = SLOT_ROW_WORDS * (uint32_t)g + s_win[l][2];
             const uint32_t rows_chunk = (k.n_sym - d0 < 64u ? k.n_sym - d0 : 64u) + shift;
             const uint32_t row_base = d0 == 0 ? 0u : d0 + 1u;           // first output row of the chunk
+            // The row phase runs at raised wave priority: a wave that has rows to emit is issued ahead
+            // of the waves still encoding, so the memory side is fed whenever anything can feed it.  With
+            // the output in one part of the device memory (stores at 5.65 TB/s) this changes nothing
+            // measurable; with the output spread over the parts (7.1 TB/s) it is worth 4.6 %
+            // (8.33 -> 7.94 ms per 10^6 packets, variants interleaved in one process).
+            __builtin_amdgcn_s_setprio(3);
             for (uint32_t r0 = 0; r0 < rows_chunk; r0 += 8u) {
                 SEC("map");
                 const bool active = r0 + (uint32_t)g < rows_chunk;
@@ -1066,6 +1076,7 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ in, float2 *__restri
                 SEC("end");
                 wave_sync();
             }
+            __builtin_amdgcn_s_setprio(0);
         }
     }
     if constexpr (!UNIFORM) sign_off(P.next_pkt, gridDim.x * (uint32_t)n_wv, lane);
