@@ -399,7 +399,8 @@ int ofdmtx_raw_tx(ofdmtx_ctx *ctx, const ofdmtx_raw_plan *plan, int qambits, int
  * device as such pieces and gives the unused ones back), usable like any device pointer for d_iq.
  * *spread (may be NULL) tells whether that worked; with less than three quarters of the device
  * free, or on any failure on the way, the buffer is an ordinary hipMalloc allocation and *spread is
- * 0.  ofdmtx_stream_free releases either kind (after a device synchronisation). */
+ * 0.  ofdmtx_stream_free releases either kind (after a device synchronisation); the buffer may
+ * outlive the context it was made with (any non-NULL ctx is accepted then). */
 int ofdmtx_stream_alloc(ofdmtx_ctx *ctx, uint64_t bytes, void **out, int *spread);
 int ofdmtx_stream_free(ofdmtx_ctx *ctx, void *ptr);
 

@@ -31,6 +31,7 @@ constexpr size_t KEEP_FREE = 2ull << 30;        // never taken from the device, 
 struct StreamBuf {
     size_t size;
     bool mapped;                                  // false: plain hipMalloc
+    int device;
 };
 std::mutex g_lock;
 std::map<void *, StreamBuf> g_bufs;
@@ -92,7 +93,7 @@ int ofdmtx_stream_alloc(ofdmtx_ctx *ctx, uint64_t bytes, void **out, int *spread
             }
         }
     }
-    StreamBuf rec = {pieces * PIECE, va != nullptr};
+    StreamBuf rec = {pieces * PIECE, va != nullptr, ctx->device};
     if (!va) {
         rec.size = (size_t)bytes;
         HIPCHK(hipMalloc(&va, (size_t)bytes));
@@ -117,7 +118,8 @@ int ofdmtx_stream_free(ofdmtx_ctx *ctx, void *ptr)
         rec = it->second;
         g_bufs.erase(it);
     }
-    HIPCHK(hipSetDevice(ctx->device));
+    // (the context is not looked into: the buffer may outlive it)
+    HIPCHK(hipSetDevice(rec.device));
     HIPCHK(hipDeviceSynchronize());                 // nothing may still be writing to it
     if (rec.mapped) {
         HIPCHK(hipMemUnmap(ptr, rec.size));
