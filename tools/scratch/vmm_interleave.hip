@@ -67,6 +67,24 @@ __global__ void __launch_bounds__(512) k_pkt_ahead(float4 *__restrict__ out, con
     }
 }
 
+// every wave reads the payloads of FOUR neighbouring packets at once (6000 contiguous bytes), then writes the four
+__global__ void __launch_bounds__(512) k_pkt_rd4(float4 *__restrict__ out, const uint32_t *__restrict__ pay, uint32_t n_pkts)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t step = gridDim.x * 8 * 4;
+    for (uint32_t p = (blockIdx.x * 8 + wave) * 4; p + 3 < n_pkts; p += step) {
+        float acc = 1.f;
+        const uint32_t *q = pay + (size_t)p * 375;
+#pragma unroll
+        for (int k = 0; k < 24; k++)
+            if (k * 64 + lane < 1500) acc += (float)q[k * 64 + lane];
+        for (int j = 0; j < 4; j++) {
+            float4 *dst = out + (size_t)(p + j) * 3000;
+            for (int i = lane; i < 3000; i += 64) dst[i] = make_float4(acc, 2.f, 3.f, (float)i);
+        }
+    }
+}
+
 int main(int argc, char **argv)
 {
     const size_t MiB = 1ull << 20, GiB = 1ull << 30;
@@ -131,7 +149,15 @@ int main(int argc, char **argv)
             CK(hipEventRecord(ev1));
             CK(hipEventSynchronize(ev1));
             CK(hipEventElapsedTime(&ms, ev0, ev1));
-            printf(" | reads one packet ahead %.3f ms\n", ms / 3);
+            printf(" | reads one packet ahead %.3f ms", ms / 3);
+            hipLaunchKernelGGL(k_pkt_rd4, dim3(512), dim3(512), 0, 0, (float4 *)bufs[b], pay, n);
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(ev0));
+            for (int r = 0; r < 3; r++) hipLaunchKernelGGL(k_pkt_rd4, dim3(512), dim3(512), 0, 0, (float4 *)bufs[b], pay, n);
+            CK(hipEventRecord(ev1));
+            CK(hipEventSynchronize(ev1));
+            CK(hipEventElapsedTime(&ms, ev0, ev1));
+            printf(" | four payloads per read %.3f ms\n", ms / 3);
             fflush(stdout);
         }
     return 0;
