@@ -102,15 +102,34 @@ __device__ __forceinline__ void sign_off(uint32_t *ctr, uint32_t n_waves, int la
 
 constexpr uint32_t CRC_POLY = 0xEDB88320u;   // ftw/ftw_crc32.cc:45
 
-// a(x) * b(x) mod P(x) in the reflected representation (x^0 = bit 31)
-__device__ __forceinline__ uint32_t crc_mulmod(uint32_t a, uint32_t b)
+// b(x) * x mod P(x) in the reflected representation (x^0 = bit 31)
+__host__ __device__ constexpr uint32_t crc_times_x(uint32_t b) { return (b >> 1) ^ (CRC_POLY & (0u - (b & 1u))); }
+
+// Shared tables of the kernels that scramble: the slicing-by-4 CRC tables, then v(x) * x^4 mod P
+// for the 16 values v of a word's low four bits (crc_mulmod); the scrambler's 127 windows of 32
+// sequence bits, then in entry 127 the window that meets stream word 0 (the SIGNAL bits stay).
+constexpr int CRC_X4 = 1024, CRC_TAB_WORDS = 1024 + 16, SCR_WORD0 = 127, SCR_TAB_WORDS = 128;
+
+__device__ __forceinline__ void fill_scramble_tables(const DevTables &T, uint32_t *s_crc, uint32_t *s_scr, int tid, int n_thr)
 {
+    for (int i = tid; i < 127; i += n_thr) s_scr[i] = T.scr_word[i];
+    if (tid == 0) s_scr[SCR_WORD0] = T.scr_word[0] >> 24;      // bits 24..31 of word 0 are SERVICE bits 0..7
+    for (int i = tid; i < 1024; i += n_thr) s_crc[i] = T.crc_tab[i];
+    if (tid < 16) s_crc[CRC_X4 + tid] = crc_times_x(crc_times_x(crc_times_x(crc_times_x((uint32_t)tid))));
+}
+
+// a(x) * b(x) mod P(x): sum over the bits of a (bit 31 = x^0) of b x^i, four bits of a per step
+// from the high powers down -- p <- p x^4 + (four selected multiples b, b x, b x^2, b x^3) -- with
+// the bits a shift by four pushes out folded back in through the 16-entry table.
+__device__ __forceinline__ uint32_t crc_mulmod(uint32_t a, uint32_t b, const uint32_t *s_crc)
+{
+    const uint32_t b1 = crc_times_x(b), b2 = crc_times_x(b1), b3 = crc_times_x(b2);
     uint32_t p = 0;
-#pragma unroll 4
-    for (int i = 0; i < 32; i++) {
-        p ^= b & (0u - (a >> 31));
-        a <<= 1;
-        b = (b >> 1) ^ (CRC_POLY & (0u - (b & 1u)));
+#pragma unroll
+    for (int s = 0; s < 32; s += 4) {
+        if (s) p = (p >> 4) ^ s_crc[CRC_X4 + (p & 15u)];
+        p ^= (b & (0u - ((a >> (s + 3)) & 1u))) ^ (b1 & (0u - ((a >> (s + 2)) & 1u))) ^
+             (b2 & (0u - ((a >> (s + 1)) & 1u))) ^ (b3 & (0u - ((a >> s) & 1u)));
     }
     return p;
 }
@@ -293,9 +312,15 @@ __device__ __forceinline__ void scramble_packet(const Pkt &k, const RegimeInfo &
     // ---- 1. MPDU in natural byte order (pu:28-36,100), Dw[-2], Dw[-1] and the tail zero
     uint32_t *Dw = A + 2;
     {
-        // A[0], A[1] = 0; A[2..7] = MAC header; A[8 + j] = payload dword j; zeros up to A[n_words + 2]
+        // A[0] byte 3 and A[1] = the SIGNAL field and the SERVICE bits (0, pu:183), every byte with its
+        // bits reversed like the MPDU's, so that step 3 treats the whole PLCP stream alike;
+        // A[2..7] = MAC header; A[8 + j] = payload dword j; zeros up to A[n_words + 2]
         if (lane < 8) {
-            uint32_t v = 0;
+            const uint32_t rev = __brev(length) >> 20;                           // pu:147-150
+            const uint32_t par = (__popc(rev & 0xFFFu) + __popc((uint32_t)ri.rate_bits)) & 1u;   // pu:153-157
+            const uint32_t field = ((uint32_t)ri.rate_bits << 20) | ((rev & 0xFFFu) << 7) | (par << 6);   // pu:174-180
+            const uint32_t sig = __brev(field) >> 8;                             // stream word 0 = __brev(sig)
+            uint32_t v = lane == 0 ? sig << 24 : sig >> 8;
             v = lane == 2 ? (0x00000008u | ((k.txtime >> 8) & 0xFFu) << 16 | (k.txtime & 0xFFu) << 24) : v;   // pu:91
             v = lane == 3 ? 0xcd086000u : v;
             v = lane == 4 ? 0x2000a637u : v;
@@ -343,7 +368,6 @@ __device__ __forceinline__ void scramble_packet(const Pkt &k, const RegimeInfo &
 
     SEC("e2_crc");
     // ---- 2. CRC-32 of the MPDU (ftw/ftw_crc32.cc:52-57)
-    uint32_t fcs;
     {
         const uint32_t c4 = (n_dw + 63u) / 64u;
         const uint32_t j0 = lane * c4;
@@ -360,36 +384,44 @@ __device__ __forceinline__ void scramble_packet(const Pkt &k, const RegimeInfo &
             }
         }
         const uint32_t endb = 4u * (j0 + c4) < mpdu_len ? 4u * (j0 + c4) : mpdu_len;
-        uint32_t part = crc_mulmod(st, T.xpow8[mpdu_len - endb]);
+        uint32_t part = crc_mulmod(st, T.xpow8[mpdu_len - endb], s_crc);
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) part ^= __shfl_xor(part, off);
-        fcs = __brev(part) ^ 0xFFFFFFFFu;      // state bit-reversed, then ^~0 (ftw/ftw_crc32.cc:58-63,75)
+        // The FCS is the state bit-reversed, then ^~0 (ftw/ftw_crc32.cc:58-63,75), appended big-endian
+        // behind the bit-reversed MPDU (pu:372): in the natural-order buffer that is ~state, low
+        // byte first, at byte mpdu_len (the words there are still zero).
+        const uint32_t fsh = 8u * (mpdu_len & 3u);
+        if (lane == 0) Dw[mpdu_len >> 2] |= ~part << fsh;
+        if (lane == 1 && fsh) Dw[(mpdu_len >> 2) + 1u] = ~part >> (32u - fsh);
     }
+    wave_sync();
 
     SEC("e3_words");
-    // ---- 3. PLCP stream words (pu:128-205) and scrambler (pu:344-367)
+    // ---- 3. PLCP stream words (pu:128-205) and scrambler (pu:344-367): stream word w = buffer bytes
+    // 4w-5 .. 4w-2 with the bit order reversed inside every byte (pu:208-218), XOR the scrambler
+    // window (32w - 24) mod 127, which advances by 16 (mod 127) from one round to the next.
     {
-        const uint32_t rev = __brev(length) >> 20;                           // pu:147-150
-        const uint32_t par = (__popc(rev & 0xFFFu) + __popc((uint32_t)ri.rate_bits)) & 1u;   // pu:153-157
-        const uint32_t field = ((uint32_t)ri.rate_bits << 20) | ((rev & 0xFFFu) << 7) | (par << 6);
-        const uint32_t F = 5u + mpdu_len, wf = F >> 2, fsh = 8u * (F & 3u);
-        const uint32_t tz = 40u + 8u * length;                               // first tail bit
+        const uint32_t t0 = ((uint32_t)lane >> 2) + 32u * ((uint32_t)lane & 3u) + 103u;     // 32 lane - 24 (mod 127)
+        uint32_t idx = t0 < 127u ? t0 : t0 - 127u;
+        uint32_t cur = lane == 0 ? (uint32_t)SCR_WORD0 : idx;
         for (uint32_t w = lane; w <= n_words; w += 64) {
-            // MPDU bytes 4w-5 .. 4w-2, bit order reversed inside every byte (pu:208-218)
-            uint32_t v = __brev((Dw[(int)w - 2] >> 24) | (Dw[(int)w - 1] << 8));
-            if (w == 0) v |= field << 8;                                     // SIGNAL; SERVICE = 0 (pu:183)
-            if (w == wf) v |= fcs >> fsh;                                    // FCS big-endian (pu:372)
-            if (w == wf + 1u && fsh) v |= fcs << (32u - fsh);
+            uint32_t v = __brev(__builtin_amdgcn_alignbyte(A[w + 1u], A[w], 3));
             if (plcp_out && 4u * w < plcp_len)
                 *reinterpret_cast<uint32_t *>(plcp_out + k.plcp_off + 4u * w) = __builtin_bswap32(v);
-            if (w == 0)
-                v ^= s_scr[0] >> 24;                  // bits 24..31 are SERVICE bits 0..7
-            else
-                v ^= s_scr[(32u * w - 24u) % 127u];
-            if (w == (tz >> 5)) v &= ~(0x3Fu << (26u - (tz & 31u)));         // six tail bits to 0, pu:361-362
+            v ^= s_scr[cur];
             U[w] = v;
             if (scr_out && 4u * w < plcp_len)
                 *reinterpret_cast<uint32_t *>(scr_out + k.plcp_off + 4u * w) = __builtin_bswap32(v);
+            idx += 16u;
+            idx = idx < 127u ? idx : idx - 127u;
+            cur = idx;
+        }
+        // six tail bits to 0 (pu:361-362), by the lane that wrote their word
+        const uint32_t tz = 40u + 8u * length;                               // first tail bit
+        if ((uint32_t)lane == ((tz >> 5) & 63u)) {
+            const uint32_t v = U[tz >> 5] & ~(0x3Fu << (26u - (tz & 31u)));
+            U[tz >> 5] = v;
+            if (scr_out) *reinterpret_cast<uint32_t *>(scr_out + k.plcp_off + 4u * (tz >> 5)) = __builtin_bswap32(v);
         }
     }
     wave_sync();
@@ -588,6 +620,176 @@ __device__ __forceinline__ void slot_words(const uint32_t (&Aw)[NA], const uint3
       __builtin_amdgcn_sched_barrier(0)), ...);
 }
 
+// --------------------------------------------------------------------------------------
+// 64-QAM rate 3/4 (regime 8): the same slot words by multiplication instead of bit by bit.
+//
+// A symbol's streams A and B are 18 units of 12 bits; unit r holds the encoder outputs of 12
+// input bits, of which puncturing (pu:316-328) keeps A bits 0,1 and B bits 0,2 of every three:
+// 16 bits, the columns c = 0..15 of row r of the interleaver's 18 x 16 block (pu:241-253).  Row
+// r = 6g + 3h + i0 feeds bit 3h + i of the constellation index of carrier 3c + g, i = (i0 - c) mod 3
+// (second permutation, pu:267-273): the 48 index bytes of a symbol are the transposed block.
+// Half a unit of one stream (5 or 6 bits, four of them kept) times a constant with four bits set
+// puts each kept bit into a byte of its own, at the bit position the row has in that byte; the
+// other partial products fall between those places (checked at compile time for every value of
+// the field, with the dropped bits cleared beforehand).  Per group g of 16 carriers this gives
+// four words -- (stream, half) = columns {8q + s, 8q + s + 2, ..} -- built from 6 rows each with
+// a bit-field extract, a 24-bit multiply and an and-or per row: 216 + 12 operations for 288 index
+// bits (two per bit otherwise).  The slot words then gather their bytes with v_perm_b32.
+namespace r8 {
+constexpr int src_bit(int sigma, int b) { return sigma == 0 ? (b < 2 ? b : b + 1) : (b == 0 ? 0 : b == 3 ? 5 : b + 1); }
+constexpr int column(int sigma, int q, int b) { return 8 * q + 2 * (3 - b) + sigma; }
+constexpr int byte_pos(int sigma, int q, int i0, int b) { return 2 - ((i0 - column(sigma, q, b)) % 3 + 3) % 3; }
+constexpr uint32_t mult(int sigma, int q, int i0)
+{
+    uint32_t k = 0;
+    for (int b = 0; b < 4; b++) k |= 1u << (8 * b + byte_pos(sigma, q, i0, b) - src_bit(sigma, b));
+    return k;
+}
+constexpr uint32_t mask(int sigma, int q, int i0)
+{
+    uint32_t m = 0;
+    for (int b = 0; b < 4; b++) m |= 1u << (8 * b + byte_pos(sigma, q, i0, b));
+    return m;
+}
+constexpr bool spread_ok(int sigma, int q, int i0)
+{
+    const int len = sigma == 0 ? 5 : 6;
+    uint32_t live = 0;
+    for (int b = 0; b < 4; b++) live |= 1u << src_bit(sigma, b);
+    if (mult(sigma, q, i0) >= (1u << 24)) return false;
+    for (uint32_t f = 0; f < (1u << len); f++) {
+        if (f & ~live) continue;
+        uint32_t want = 0;
+        for (int b = 0; b < 4; b++) want |= ((f >> src_bit(sigma, b)) & 1u) << (8 * b + byte_pos(sigma, q, i0, b));
+        if (((f * mult(sigma, q, i0)) & mask(sigma, q, i0)) != want) return false;
+    }
+    return true;
+}
+static_assert(spread_ok(0, 0, 0) && spread_ok(0, 0, 1) && spread_ok(0, 0, 2) && spread_ok(0, 1, 0) &&
+              spread_ok(0, 1, 1) && spread_ok(0, 1, 2) && spread_ok(1, 0, 0) && spread_ok(1, 0, 1) &&
+              spread_ok(1, 0, 2) && spread_ok(1, 1, 0) && spread_ok(1, 1, 1) && spread_ok(1, 1, 2),
+              "a partial product collides with a kept bit");
+
+// bits n0 .. n0 + LEN - 1 of a stream held as MSB-first words, right-aligned
+template <int N0, int LEN, int NA>
+__device__ __forceinline__ uint32_t field(const uint32_t (&W)[NA])
+{
+    constexpr int w = N0 >> 5, o = N0 & 31;
+    if constexpr (o + LEN <= 32)
+        return (W[w] >> (32 - o - LEN)) & ((1u << LEN) - 1u);
+    else
+        return __funnelshift_l(W[w + 1], W[w], o) >> (32 - LEN);
+}
+
+// stream bits that puncturing drops, cleared: A keeps n % 3 in {0, 1}, B keeps n % 3 in {0, 2}
+constexpr uint32_t keep_mask(int sigma, int word)
+{
+    uint32_t m = 0;
+    for (int j = 0; j < 32; j++)
+        if ((32 * word + j) % 3 != (sigma == 0 ? 2 : 1)) m |= 1u << (31 - j);
+    return m;
+}
+
+// one row's contribution to the word of (group G, stream SIGMA, half Q)
+// The three masks (one per rotation of the rows over the bytes), held in scalar registers so that
+// "(product & mask) | word so far" is one v_and_or_b32.
+struct Masks { uint32_t m[3]; };
+constexpr int mask_class(int sigma, int q, int i0) { return mask(sigma, q, i0) == mask(0, 0, 0) ? 0 : mask(sigma, q, i0) == mask(0, 0, 1) ? 1 : 2; }
+static_assert(mask(0, 0, 2) != mask(0, 0, 0) && mask(0, 0, 2) != mask(0, 0, 1) && mask(1, 1, 1) == mask(0, 0, mask_class(1, 1, 1)),
+              "three masks");
+
+template <int G, int SIGMA, int Q, int RHO, int NA>
+__device__ __forceinline__ uint32_t row_bits(const uint32_t (&Aw)[NA], const uint32_t (&Bw)[NA], const Masks &mk, uint32_t acc)
+{
+    constexpr int n0 = 12 * (6 * G + RHO) + 6 * Q;
+    const uint32_t f = SIGMA == 0 ? field<n0, 5>(Aw) : field<n0, 6>(Bw);
+    const uint32_t prod = __umul24(f, mult(SIGMA, Q, RHO % 3));
+    uint32_t d;
+    // (written out: the compiler regroups a chain of these into three ands and a v_or3_b32)
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(prod), "s"(mk.m[mask_class(SIGMA, Q, RHO % 3)]), "v"(acc));
+    return d;
+}
+
+// index bytes of carriers 3c + G, c = column(SIGMA, Q, b), in byte b
+template <int G, int SIGMA, int Q, int NA>
+__device__ __forceinline__ uint32_t group_word(const uint32_t (&Aw)[NA], const uint32_t (&Bw)[NA], const Masks &mk)
+{
+    uint32_t hi = row_bits<G, SIGMA, Q, 0>(Aw, Bw, mk, 0u);
+    hi = row_bits<G, SIGMA, Q, 1>(Aw, Bw, mk, hi);
+    hi = row_bits<G, SIGMA, Q, 2>(Aw, Bw, mk, hi);
+    uint32_t lo = row_bits<G, SIGMA, Q, 3>(Aw, Bw, mk, 0u);
+    lo = row_bits<G, SIGMA, Q, 4>(Aw, Bw, mk, lo);
+    lo = row_bits<G, SIGMA, Q, 5>(Aw, Bw, mk, lo);
+    return (hi << 3) | lo;
+}
+
+// where the index byte of data carrier m lies: word 4g + 2 sigma + q of the twelve, byte b
+constexpr int word_of(int m) { return 4 * (m % 3) + 2 * ((m / 3) & 1) + (m / 3) / 8; }
+constexpr int byte_of(int m) { return 3 - ((m / 3) % 8) / 2; }
+
+// v_perm_b32 selector that moves into slot word WORD the bytes it takes from carrier word SRC and
+// keeps the others (selector bytes 0-3: the word so far, 4-7: the carrier word); 0 if it takes none
+template <int WORD, int SRC>
+constexpr uint32_t gather_sel()
+{
+    uint32_t sel = 0;
+    bool any = false;
+    for (int b = 0; b < 4; b++) {
+        const int c = bin_code(slot_row_bin(4 * WORD + b));
+        if (c >= 0 && word_of(c) == SRC) {
+            sel |= (uint32_t)(4 + byte_of(c)) << (8 * b);
+            any = true;
+        } else {
+            sel |= (uint32_t)b << (8 * b);
+        }
+    }
+    return any ? sel : 0u;
+}
+
+template <int WORD, int SRC>
+__device__ __forceinline__ void gather_from(uint32_t &v, const uint32_t (&cw)[12])
+{
+    constexpr uint32_t sel = gather_sel<WORD, SRC>();
+    if constexpr (sel != 0u) v = __builtin_amdgcn_perm(cw[SRC], v, sel);
+}
+
+template <int WORD, int... SRC>
+__device__ __forceinline__ uint32_t slot_word(const uint32_t (&cw)[12], uint32_t neg, std::integer_sequence<int, SRC...>)
+{
+    uint32_t v = 0;
+    (gather_from<WORD, SRC>(v, cw), ...);
+    v |= SlotConst<6, WORD>::value;
+    if constexpr (SlotConst<6, WORD>::flip != 0u) v ^= neg ? SlotConst<6, WORD>::flip : 0u;
+    return v;
+}
+
+template <int NA, int... WORD>
+__device__ __forceinline__ void slot_words(uint32_t (&Aw)[NA], uint32_t (&Bw)[NA], uint32_t neg, uint32_t *dst,
+                                           std::integer_sequence<int, WORD...>)
+{
+    static_assert(NA == 7, "216 stream bits");
+    // (the empty asm keeps the compiler from folding the clearing into every field extract,
+    // which would turn each one-instruction bit-field extract into a shift and an and)
+#pragma unroll
+    for (int i = 0; i < NA; i++) {
+        Aw[i] &= keep_mask(0, i);
+        Bw[i] &= keep_mask(1, i);
+        asm volatile("" : "+v"(Aw[i]), "+v"(Bw[i]));
+    }
+    Masks mk = {{mask(0, 0, 0), mask(0, 0, 1), mask(0, 0, 2)}};
+    asm volatile("" : "+s"(mk.m[0]), "+s"(mk.m[1]), "+s"(mk.m[2]));
+    uint32_t cw[12];
+#define R8_GROUP(G_)                                                                              \
+    cw[4 * G_ + 0] = group_word<G_, 0, 0>(Aw, Bw, mk); __builtin_amdgcn_sched_barrier(0);         \
+    cw[4 * G_ + 1] = group_word<G_, 0, 1>(Aw, Bw, mk); __builtin_amdgcn_sched_barrier(0);         \
+    cw[4 * G_ + 2] = group_word<G_, 1, 0>(Aw, Bw, mk); __builtin_amdgcn_sched_barrier(0);         \
+    cw[4 * G_ + 3] = group_word<G_, 1, 1>(Aw, Bw, mk); __builtin_amdgcn_sched_barrier(0);
+    R8_GROUP(0) R8_GROUP(1) R8_GROUP(2)
+#undef R8_GROUP
+    ((dst[WORD] = slot_word<WORD>(cw, neg, std::make_integer_sequence<int, 12>{})), ...);
+}
+}   // namespace r8
+
 // Slot rows of the DATA symbols with 0-based index d0 + lane (the SIGNAL symbol is not handled here), one
 // lane per symbol, into the row SI points at + lane.  Encoder, puncturing and interleaver as in
 // encode_data_symbols; the pilot polarity of DATA symbol d is entry (pilot_base + 1 + d) % 127.
@@ -621,7 +823,10 @@ __device__ __forceinline__ void symbol_slots(const uint32_t *U, uint32_t *SI, ui
             Bw[i] = common ^ y5 ^ y4;
         }
         const uint32_t neg = pilot_negative((pilot_base + 1u + d) % 127u, pneg_lo, pneg_hi);
-        slot_words<NBPSC, PUNCT>(Aw, Bw, neg, SI + SLOT_ROW_WORDS * lane, std::make_integer_sequence<int, SLOT_ROW_WORDS>{});
+        if constexpr (NBPSC == 6 && PUNCT == 1)
+            r8::slot_words(Aw, Bw, neg, SI + SLOT_ROW_WORDS * lane, std::make_integer_sequence<int, SLOT_ROW_WORDS>{});
+        else
+            slot_words<NBPSC, PUNCT>(Aw, Bw, neg, SI + SLOT_ROW_WORDS * lane, std::make_integer_sequence<int, SLOT_ROW_WORDS>{});
     }
 }
 
@@ -659,12 +864,11 @@ k_encode_bits(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads,
 {
     __shared__ __align__(16) uint32_t s_a[ENC_WAVES][ENC_A_WORDS];
     __shared__ __align__(16) uint32_t s_u[ENC_WAVES][ENC_U_WORDS];
-    __shared__ uint32_t s_crc[1024];
-    __shared__ uint32_t s_scr[127];
+    __shared__ uint32_t s_crc[CRC_TAB_WORDS];
+    __shared__ uint32_t s_scr[SCR_TAB_WORDS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < 127; i += 64 * ENC_WAVES) s_scr[i] = T.scr_word[i];
-    for (int i = tid; i < 1024; i += 64 * ENC_WAVES) s_crc[i] = T.crc_tab[i];
+    fill_scramble_tables(T, s_crc, s_scr, tid, 64 * ENC_WAVES);
     __syncthreads();
 
     uint32_t *A = s_a[wave];
@@ -815,8 +1019,8 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ in, float2 *__restri
      uint32_t u_off, uint32_t wave_words)
 {
     extern __shared__ __align__(16) uint32_t s_dyn[];
-    __shared__ uint32_t s_crc[FROM_MSG ? 1 : 1024];
-    __shared__ uint32_t s_scr[FROM_MSG ? 1 : 128];
+    __shared__ uint32_t s_crc[FROM_MSG ? 1 : CRC_TAB_WORDS];
+    __shared__ uint32_t s_scr[FROM_MSG ? 1 : SCR_TAB_WORDS];
     __shared__ float2 s_lut[LUT_SIZE];
     __shared__ __align__(16) float2 s_pre[(PNC ? PNC_PRE_ROWS : PRE_ROWS) * SYM_LEN];   // preamble rows, amplitude applied
     __shared__ float2 s_tw[64];
@@ -849,10 +1053,7 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ in, float2 *__restri
     }
     // 1/sqrt(64) (examples/ftw_ofdm.py:126) is a power of two: (x*0.125)*amp == x*(0.125*amp)
     const float scale = 0.125f * amp;
-    if constexpr (!FROM_MSG) {
-        for (int i = tid; i < 127; i += n_thr) s_scr[i] = T.scr_word[i];
-        for (int i = tid; i < 1024; i += n_thr) s_crc[i] = T.crc_tab[i];
-    }
+    if constexpr (!FROM_MSG) fill_scramble_tables(T, s_crc, s_scr, tid, n_thr);
     for (int i = tid; i < LUT_SIZE; i += n_thr) s_lut[i] = T.lut[i];
     if constexpr (PNC) {
         // Row r of the packet's preamble = table row (pre_map >> 4r) & 15, or zeros (15).  The PNC
