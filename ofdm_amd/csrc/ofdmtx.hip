@@ -1103,6 +1103,27 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ in, float2 *__restri
     // from a counter instead (lane 0 asks, the wave reads the answer from lane 0).
     // A draw takes P.grab_tx consecutive packets: one address sustains only ~10^8 atomics per
     // second, which a batch of short packets would exceed at one draw per packet.
+    // Uniform batches of mapper messages: the first AHEAD_WORDS * 64 words of the NEXT packet's message are
+    // requested before this packet's rows are emitted and wait in registers.  Without the preamble
+    // and gap rows (the map + IFFT + CP stage on its own) nothing else covers the time between a
+    // wave's last row and the arrival of its next message.
+    // (Tried for the payloads as well: no gain -- there the preamble and gap rows, written before the
+    // encoder starts, already cover that time.  The PNC instantiation has no registers to spare.)
+    constexpr bool AHEAD = UNIFORM && FROM_MSG && !PNC;
+    constexpr int AHEAD_WORDS = 9;                        // 576 words = 2304 message bytes
+    [[maybe_unused]] uint32_t ahead[AHEAD_WORDS];
+    [[maybe_unused]] auto fetch_ahead = [&](uint32_t pn) {
+        if (pn < P.n_pkts) {
+            const Pkt kn = load_pkt<UNIFORM>(P, pn);
+            const RegimeInfo rn = regime_info(REGIME ? REGIME : (int)kn.regime);
+            const uint32_t n_mw = (6u + kn.n_sym * (uint32_t)rn.n_cbps / 8u + 3u) / 4u;
+            const uint32_t *mp = reinterpret_cast<const uint32_t *>(in + kn.msg_off);
+#pragma unroll
+            for (int kk = 0; kk < AHEAD_WORDS; kk++)
+                ahead[kk] = (uint32_t)lane + 64u * kk < n_mw ? mp[(uint32_t)lane + 64u * kk] : 0u;
+        }
+    };
+
     uint32_t p_end = 0;
     auto next_packet = [&](uint32_t prev, bool first) -> uint32_t {
         if constexpr (UNIFORM) {
@@ -1116,6 +1137,7 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ in, float2 *__restri
             return v;
         }
     };
+    if constexpr (AHEAD) fetch_ahead(next_packet(0, true));
     for (uint32_t p = next_packet(0, true); p < P.n_pkts; p = next_packet(p, false)) {
         const Pkt k = load_pkt<UNIFORM>(P, p);
         const RegimeInfo ri = regime_info(REGIME ? REGIME : (int)k.regime);
@@ -1131,7 +1153,12 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ in, float2 *__restri
             const uint32_t *mp = reinterpret_cast<const uint32_t *>(in + k.msg_off);
             // (all loads of a round first: a loop of load -> LDS write waits for every load in turn)
             constexpr int K = 8;
-            for (uint32_t w0 = (uint32_t)lane; w0 < n_mw + 2u; w0 += 64u * K) {
+            if constexpr (AHEAD) {
+#pragma unroll
+                for (int kk = 0; kk < AHEAD_WORDS; kk++)
+                    if ((uint32_t)lane + 64u * kk < n_mw + 2u) U[(uint32_t)lane + 64u * kk] = __builtin_bswap32(ahead[kk]);
+            }
+            for (uint32_t w0 = (uint32_t)lane + (AHEAD ? 64u * AHEAD_WORDS : 0u); w0 < n_mw + 2u; w0 += 64u * K) {
                 uint32_t mv[K];
 #pragma unroll
                 for (int kk = 0; kk < K; kk++) mv[kk] = w0 + 64u * kk < n_mw ? mp[w0 + 64u * kk] : 0u;
@@ -1218,6 +1245,8 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ in, float2 *__restri
             // Lane-dependent addressing of the row phase, derived here from an opaque copy of the
             // lane number: hoisted out of the packet loop these ~25 registers would stay live
             // through the encoder, whose bit table needs the register file to itself.
+            if constexpr (AHEAD)
+                if (d0 == 0) fetch_ahead(next_packet(p, false));
             int lane_r = lane;
             asm volatile("" : "+v"(lane_r));
             const int l = lane_r & 7, g = lane_r >> 3;
