@@ -217,6 +217,164 @@ __device__ __forceinline__ void punctured_bits(const uint32_t (&Aw)[NA], const u
     (move_coded_bit<PUNCT, Q, Q>(Aw, Bw, out), ...);
 }
 
+// --------------------------------------------------------------------------------------
+// 64-QAM rate 3/4 (regime 8): interleaving by multiplication instead of bit by bit.
+//
+// A symbol's streams A and B are 18 units of 12 bits; unit r holds the encoder outputs of 12
+// input bits, of which puncturing (pu:316-328) keeps A bits 0,1 and B bits 0,2 of every three:
+// 16 bits, the columns c = 0..15 of row r of the interleaver's 18 x 16 block (pu:241-253).  Row
+// r = 6g + 3h + i0 feeds bit 3h + i of the constellation index of carrier 3c + g, i = (i0 - c) mod 3
+// (second permutation, pu:267-273): the 48 index bytes of a symbol are the transposed block.
+// Half a unit of one stream (5 or 6 bits, four of them kept) times a constant with four bits set
+// puts each kept bit into a byte of its own, at the bit position the row has in that byte; the
+// other partial products fall between those places (checked at compile time for every value of
+// the field, with the dropped bits cleared beforehand).  Per group g of 16 carriers this gives
+// four words -- (stream, half) = columns {8q + s, 8q + s + 2, ..} -- built from 6 rows each with
+// a bit-field extract, a 24-bit multiply and an and-or per row: 216 + 12 operations for 288 index
+// bits (two per bit otherwise).  The fused kernel's slot words then gather their bytes with
+// v_perm_b32; the mapper message takes them column by column (message_words).
+namespace r8 {
+constexpr int src_bit(int sigma, int b) { return sigma == 0 ? (b < 2 ? b : b + 1) : (b == 0 ? 0 : b == 3 ? 5 : b + 1); }
+constexpr int column(int sigma, int q, int b) { return 8 * q + 2 * (3 - b) + sigma; }
+constexpr int byte_pos(int sigma, int q, int i0, int b) { return 2 - ((i0 - column(sigma, q, b)) % 3 + 3) % 3; }
+constexpr uint32_t mult(int sigma, int q, int i0)
+{
+    uint32_t k = 0;
+    for (int b = 0; b < 4; b++) k |= 1u << (8 * b + byte_pos(sigma, q, i0, b) - src_bit(sigma, b));
+    return k;
+}
+constexpr uint32_t mask(int sigma, int q, int i0)
+{
+    uint32_t m = 0;
+    for (int b = 0; b < 4; b++) m |= 1u << (8 * b + byte_pos(sigma, q, i0, b));
+    return m;
+}
+constexpr bool spread_ok(int sigma, int q, int i0)
+{
+    const int len = sigma == 0 ? 5 : 6;
+    uint32_t live = 0;
+    for (int b = 0; b < 4; b++) live |= 1u << src_bit(sigma, b);
+    if (mult(sigma, q, i0) >= (1u << 24)) return false;
+    for (uint32_t f = 0; f < (1u << len); f++) {
+        if (f & ~live) continue;
+        uint32_t want = 0;
+        for (int b = 0; b < 4; b++) want |= ((f >> src_bit(sigma, b)) & 1u) << (8 * b + byte_pos(sigma, q, i0, b));
+        if (((f * mult(sigma, q, i0)) & mask(sigma, q, i0)) != want) return false;
+    }
+    return true;
+}
+static_assert(spread_ok(0, 0, 0) && spread_ok(0, 0, 1) && spread_ok(0, 0, 2) && spread_ok(0, 1, 0) &&
+              spread_ok(0, 1, 1) && spread_ok(0, 1, 2) && spread_ok(1, 0, 0) && spread_ok(1, 0, 1) &&
+              spread_ok(1, 0, 2) && spread_ok(1, 1, 0) && spread_ok(1, 1, 1) && spread_ok(1, 1, 2),
+              "a partial product collides with a kept bit");
+
+// bits n0 .. n0 + LEN - 1 of a stream held as MSB-first words, right-aligned
+template <int N0, int LEN, int NA>
+__device__ __forceinline__ uint32_t field(const uint32_t (&W)[NA])
+{
+    constexpr int w = N0 >> 5, o = N0 & 31;
+    if constexpr (o + LEN <= 32)
+        return (W[w] >> (32 - o - LEN)) & ((1u << LEN) - 1u);
+    else
+        return __funnelshift_l(W[w + 1], W[w], o) >> (32 - LEN);
+}
+
+// stream bits that puncturing drops, cleared: A keeps n % 3 in {0, 1}, B keeps n % 3 in {0, 2}
+constexpr uint32_t keep_mask(int sigma, int word)
+{
+    uint32_t m = 0;
+    for (int j = 0; j < 32; j++)
+        if ((32 * word + j) % 3 != (sigma == 0 ? 2 : 1)) m |= 1u << (31 - j);
+    return m;
+}
+
+// one row's contribution to the word of (group G, stream SIGMA, half Q)
+// The three masks (one per rotation of the rows over the bytes), held in scalar registers so that
+// "(product & mask) | word so far" is one v_and_or_b32.
+struct Masks { uint32_t m[3]; };
+constexpr int mask_class(int sigma, int q, int i0) { return mask(sigma, q, i0) == mask(0, 0, 0) ? 0 : mask(sigma, q, i0) == mask(0, 0, 1) ? 1 : 2; }
+static_assert(mask(0, 0, 2) != mask(0, 0, 0) && mask(0, 0, 2) != mask(0, 0, 1) && mask(1, 1, 1) == mask(0, 0, mask_class(1, 1, 1)),
+              "three masks");
+
+template <int G, int SIGMA, int Q, int RHO, int NA>
+__device__ __forceinline__ uint32_t row_bits(const uint32_t (&Aw)[NA], const uint32_t (&Bw)[NA], const Masks &mk, uint32_t acc)
+{
+    constexpr int n0 = 12 * (6 * G + RHO) + 6 * Q;
+    const uint32_t f = SIGMA == 0 ? field<n0, 5>(Aw) : field<n0, 6>(Bw);
+    const uint32_t prod = __umul24(f, mult(SIGMA, Q, RHO % 3));
+    uint32_t d;
+    // (written out: the compiler regroups a chain of these into three ands and a v_or3_b32)
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(prod), "s"(mk.m[mask_class(SIGMA, Q, RHO % 3)]), "v"(acc));
+    return d;
+}
+
+// index bytes of carriers 3c + G, c = column(SIGMA, Q, b), in byte b
+template <int G, int SIGMA, int Q, int NA>
+__device__ __forceinline__ uint32_t group_word(const uint32_t (&Aw)[NA], const uint32_t (&Bw)[NA], const Masks &mk)
+{
+    uint32_t hi = row_bits<G, SIGMA, Q, 0>(Aw, Bw, mk, 0u);
+    hi = row_bits<G, SIGMA, Q, 1>(Aw, Bw, mk, hi);
+    hi = row_bits<G, SIGMA, Q, 2>(Aw, Bw, mk, hi);
+    uint32_t lo = row_bits<G, SIGMA, Q, 3>(Aw, Bw, mk, 0u);
+    lo = row_bits<G, SIGMA, Q, 4>(Aw, Bw, mk, lo);
+    lo = row_bits<G, SIGMA, Q, 5>(Aw, Bw, mk, lo);
+    return (hi << 3) | lo;
+}
+
+// where the index byte of data carrier m lies: word 4g + 2 sigma + q of the twelve, byte b
+constexpr int word_of(int m) { return 4 * (m % 3) + 2 * ((m / 3) & 1) + (m / 3) / 8; }
+constexpr int byte_of(int m) { return 3 - ((m / 3) % 8) / 2; }
+
+// The twelve words of a symbol: the index byte of carrier m in byte byte_of(m) of cw[word_of(m)].
+// Clears the dropped bits of Aw / Bw on the way.
+template <int NA>
+__device__ __forceinline__ void carrier_words(uint32_t (&Aw)[NA], uint32_t (&Bw)[NA], uint32_t (&cw)[12])
+{
+    static_assert(NA == 7, "216 stream bits");
+    // (the empty asm keeps the compiler from folding the clearing into every field extract,
+    // which would turn each one-instruction bit-field extract into a shift and an and)
+#pragma unroll
+    for (int i = 0; i < NA; i++) {
+        Aw[i] &= keep_mask(0, i);
+        Bw[i] &= keep_mask(1, i);
+        asm volatile("" : "+v"(Aw[i]), "+v"(Bw[i]));
+    }
+    Masks mk = {{mask(0, 0, 0), mask(0, 0, 1), mask(0, 0, 2)}};
+    asm volatile("" : "+s"(mk.m[0]), "+s"(mk.m[1]), "+s"(mk.m[2]));
+#define R8_GROUP(G_)                                                                              \
+    cw[4 * G_ + 0] = group_word<G_, 0, 0>(Aw, Bw, mk); __builtin_amdgcn_sched_barrier(0);         \
+    cw[4 * G_ + 1] = group_word<G_, 0, 1>(Aw, Bw, mk); __builtin_amdgcn_sched_barrier(0);         \
+    cw[4 * G_ + 2] = group_word<G_, 1, 0>(Aw, Bw, mk); __builtin_amdgcn_sched_barrier(0);         \
+    cw[4 * G_ + 3] = group_word<G_, 1, 1>(Aw, Bw, mk); __builtin_amdgcn_sched_barrier(0);
+    R8_GROUP(0) R8_GROUP(1) R8_GROUP(2)
+#undef R8_GROUP
+}
+
+// The symbol's 288 interleaved bits as nine MSB-first words: carrier m's six index bits are message
+// bits 6m .. 6m + 5 (ftw/ftw_ofdm_mapper.cc:262-275 reads them MSB first), i.e. column c of the block
+// contributes 18 bits -- carriers 3c, 3c + 1, 3c + 2 -- at bit 18c.
+template <int C>
+__device__ __forceinline__ void put_column(const uint32_t (&cw)[12], uint32_t (&out)[9])
+{
+    constexpr int w = word_of(3 * C) & 3, sh = 8 * byte_of(3 * C);      // the same place in each group's four words
+    const uint32_t v = (((cw[w] >> sh) & 63u) << 12) | (((cw[4 + w] >> sh) & 63u) << 6) | ((cw[8 + w] >> sh) & 63u);
+    constexpr int pos = 18 * C, k = pos >> 5, o = pos & 31;             // 18 bits from bit o of word k on
+    if constexpr (o + 18 <= 32) {
+        out[k] |= v << (32 - 18 - o);
+    } else {
+        out[k] |= v >> (o + 18 - 32);
+        out[k + 1] |= v << (64 - 18 - o);
+    }
+}
+template <int... C>
+__device__ __forceinline__ void message_words(const uint32_t (&cw)[12], uint32_t (&out)[9], std::integer_sequence<int, C...>)
+{
+#pragma unroll
+    for (int i = 0; i < 9; i++) out[i] = 0;
+    (put_column<C>(cw, out), ...);
+}
+}   // namespace r8
+
 // DATA symbols of one packet, one lane per symbol.  OUTW: MSB-first words, word 2 holds the
 // first 32 interleaved DATA bits (words 0,1 carry the SIGNAL symbol).
 //
@@ -270,7 +428,13 @@ __device__ __forceinline__ void encode_data_symbols(const uint32_t *U, uint32_t 
         }
 
         uint32_t out[NW];
-        interleave_bits<NBPSC, PUNCT>(Aw, Bw, out, std::make_integer_sequence<int, NW>{});
+        if constexpr (NBPSC == 6 && PUNCT == 1) {
+            uint32_t cw[12];
+            r8::carrier_words(Aw, Bw, cw);
+            r8::message_words(cw, out, std::make_integer_sequence<int, 16>{});
+        } else {
+            interleave_bits<NBPSC, PUNCT>(Aw, Bw, out, std::make_integer_sequence<int, NW>{});
+        }
 
         if (N % 32 == 0) {
 #pragma unroll
@@ -290,11 +454,29 @@ __device__ __forceinline__ void encode_data_symbols(const uint32_t *U, uint32_t 
 // words in U[0 .. n_words].  A: >= n_words + 3 words of LDS (natural-order MPDU, dead afterwards);
 // U: >= n_words + 2 words.  plcp_out / scr_out are optional taps (global memory).  K: rounds of
 // 64 payload words loaded before the first is used.
+// One round of a packet's payload words, requested ahead of their use: the aligned dwords
+// q[lane + 64 kk], kk < K, of the payload that starts at pp (0 beyond it).
 template <int K>
+struct PayloadAhead {
+    uint32_t w[K];
+    __device__ __forceinline__ void fetch(const uint8_t *pp, uint32_t pay_len, int lane)
+    {
+        const uint32_t al = (uint32_t)(reinterpret_cast<uintptr_t>(pp) & 3u);
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(pp - al);
+        const uint32_t n_pw = (pay_len + 3u) / 4u;
+#pragma unroll
+        for (int kk = 0; kk < K; kk++) w[kk] = (uint32_t)lane + 64u * kk < n_pw ? q[(uint32_t)lane + 64u * kk] : 0u;
+    }
+};
+
+// AHEAD: `ahead` holds the first round of this packet's payload words on entry; once they are in
+// LDS the first round of the packet whose payload starts at next_pp (nullptr: none) is requested.
+template <int K, bool AHEAD = false>
 __device__ __forceinline__ void scramble_packet(const Pkt &k, const RegimeInfo &ri, const DevTables &T,
                                                 const uint8_t *__restrict__ payloads, uint32_t *A, uint32_t *U,
                                                 const uint32_t *s_crc, const uint32_t *s_scr, int lane_in,
-                                                uint8_t *plcp_out, uint8_t *scr_out)
+                                                uint8_t *plcp_out, uint8_t *scr_out, PayloadAhead<K> *ahead = nullptr,
+                                                const uint8_t *next_pp = nullptr, uint32_t next_len = 0)
 {
     // Opaque copy of the lane number: in a uniform plan every per-lane address below is invariant
     // over the caller's packet loop; hoisted out of it, they would take registers that the
@@ -342,7 +524,8 @@ __device__ __forceinline__ void scramble_packet(const Pkt &k, const RegimeInfo &
 #pragma unroll
             for (int kk = 0; kk < K; kk++) {
                 const uint32_t j = j0 + 64u * kk;
-                lo[kk] = j < n_pw ? q[j] : 0u;
+                if (AHEAD && j0 < 64u) lo[kk] = ahead->w[kk];
+                else lo[kk] = j < n_pw ? q[j] : 0u;
             }
             if (al) {
 #pragma unroll
@@ -363,6 +546,8 @@ __device__ __forceinline__ void scramble_packet(const Pkt &k, const RegimeInfo &
                 }
             }
         }
+        if constexpr (AHEAD)
+            if (next_pp) ahead->fetch(next_pp, next_len, lane);
     }
     wave_sync();
 
@@ -435,9 +620,11 @@ template <int REGIME>
 __device__ __forceinline__ void encode_packet(const Pkt &k, const RegimeInfo &ri, const DevTables &T,
                                      const uint8_t *__restrict__ payloads, uint32_t *A, uint32_t *U,
                                      const uint32_t *s_crc, const uint32_t *s_scr, int lane,
-                                     uint8_t *plcp_out, uint8_t *scr_out, uint8_t *cod_out)
+                                     uint8_t *plcp_out, uint8_t *scr_out, uint8_t *cod_out,
+                                     PayloadAhead<8> *ahead = nullptr, const uint8_t *next_pp = nullptr, uint32_t next_len = 0)
 {
-    scramble_packet<8>(k, ri, T, payloads, A, U, s_crc, s_scr, lane, plcp_out, scr_out);
+    if (ahead) scramble_packet<8, true>(k, ri, T, payloads, A, U, s_crc, s_scr, lane, plcp_out, scr_out, ahead, next_pp, next_len);
+    else scramble_packet<8>(k, ri, T, payloads, A, U, s_crc, s_scr, lane, plcp_out, scr_out);
 
     SEC("e4_signal");
     // ---- 4. SIGNAL symbol: 48 coded bits, N = 48 first permutation only (pu:245-249)
@@ -620,113 +807,9 @@ __device__ __forceinline__ void slot_words(const uint32_t (&Aw)[NA], const uint3
       __builtin_amdgcn_sched_barrier(0)), ...);
 }
 
-// --------------------------------------------------------------------------------------
-// 64-QAM rate 3/4 (regime 8): the same slot words by multiplication instead of bit by bit.
-//
-// A symbol's streams A and B are 18 units of 12 bits; unit r holds the encoder outputs of 12
-// input bits, of which puncturing (pu:316-328) keeps A bits 0,1 and B bits 0,2 of every three:
-// 16 bits, the columns c = 0..15 of row r of the interleaver's 18 x 16 block (pu:241-253).  Row
-// r = 6g + 3h + i0 feeds bit 3h + i of the constellation index of carrier 3c + g, i = (i0 - c) mod 3
-// (second permutation, pu:267-273): the 48 index bytes of a symbol are the transposed block.
-// Half a unit of one stream (5 or 6 bits, four of them kept) times a constant with four bits set
-// puts each kept bit into a byte of its own, at the bit position the row has in that byte; the
-// other partial products fall between those places (checked at compile time for every value of
-// the field, with the dropped bits cleared beforehand).  Per group g of 16 carriers this gives
-// four words -- (stream, half) = columns {8q + s, 8q + s + 2, ..} -- built from 6 rows each with
-// a bit-field extract, a 24-bit multiply and an and-or per row: 216 + 12 operations for 288 index
-// bits (two per bit otherwise).  The slot words then gather their bytes with v_perm_b32.
+
+// The fused kernel's slot rows of a 64-QAM r3/4 symbol from its twelve carrier words.
 namespace r8 {
-constexpr int src_bit(int sigma, int b) { return sigma == 0 ? (b < 2 ? b : b + 1) : (b == 0 ? 0 : b == 3 ? 5 : b + 1); }
-constexpr int column(int sigma, int q, int b) { return 8 * q + 2 * (3 - b) + sigma; }
-constexpr int byte_pos(int sigma, int q, int i0, int b) { return 2 - ((i0 - column(sigma, q, b)) % 3 + 3) % 3; }
-constexpr uint32_t mult(int sigma, int q, int i0)
-{
-    uint32_t k = 0;
-    for (int b = 0; b < 4; b++) k |= 1u << (8 * b + byte_pos(sigma, q, i0, b) - src_bit(sigma, b));
-    return k;
-}
-constexpr uint32_t mask(int sigma, int q, int i0)
-{
-    uint32_t m = 0;
-    for (int b = 0; b < 4; b++) m |= 1u << (8 * b + byte_pos(sigma, q, i0, b));
-    return m;
-}
-constexpr bool spread_ok(int sigma, int q, int i0)
-{
-    const int len = sigma == 0 ? 5 : 6;
-    uint32_t live = 0;
-    for (int b = 0; b < 4; b++) live |= 1u << src_bit(sigma, b);
-    if (mult(sigma, q, i0) >= (1u << 24)) return false;
-    for (uint32_t f = 0; f < (1u << len); f++) {
-        if (f & ~live) continue;
-        uint32_t want = 0;
-        for (int b = 0; b < 4; b++) want |= ((f >> src_bit(sigma, b)) & 1u) << (8 * b + byte_pos(sigma, q, i0, b));
-        if (((f * mult(sigma, q, i0)) & mask(sigma, q, i0)) != want) return false;
-    }
-    return true;
-}
-static_assert(spread_ok(0, 0, 0) && spread_ok(0, 0, 1) && spread_ok(0, 0, 2) && spread_ok(0, 1, 0) &&
-              spread_ok(0, 1, 1) && spread_ok(0, 1, 2) && spread_ok(1, 0, 0) && spread_ok(1, 0, 1) &&
-              spread_ok(1, 0, 2) && spread_ok(1, 1, 0) && spread_ok(1, 1, 1) && spread_ok(1, 1, 2),
-              "a partial product collides with a kept bit");
-
-// bits n0 .. n0 + LEN - 1 of a stream held as MSB-first words, right-aligned
-template <int N0, int LEN, int NA>
-__device__ __forceinline__ uint32_t field(const uint32_t (&W)[NA])
-{
-    constexpr int w = N0 >> 5, o = N0 & 31;
-    if constexpr (o + LEN <= 32)
-        return (W[w] >> (32 - o - LEN)) & ((1u << LEN) - 1u);
-    else
-        return __funnelshift_l(W[w + 1], W[w], o) >> (32 - LEN);
-}
-
-// stream bits that puncturing drops, cleared: A keeps n % 3 in {0, 1}, B keeps n % 3 in {0, 2}
-constexpr uint32_t keep_mask(int sigma, int word)
-{
-    uint32_t m = 0;
-    for (int j = 0; j < 32; j++)
-        if ((32 * word + j) % 3 != (sigma == 0 ? 2 : 1)) m |= 1u << (31 - j);
-    return m;
-}
-
-// one row's contribution to the word of (group G, stream SIGMA, half Q)
-// The three masks (one per rotation of the rows over the bytes), held in scalar registers so that
-// "(product & mask) | word so far" is one v_and_or_b32.
-struct Masks { uint32_t m[3]; };
-constexpr int mask_class(int sigma, int q, int i0) { return mask(sigma, q, i0) == mask(0, 0, 0) ? 0 : mask(sigma, q, i0) == mask(0, 0, 1) ? 1 : 2; }
-static_assert(mask(0, 0, 2) != mask(0, 0, 0) && mask(0, 0, 2) != mask(0, 0, 1) && mask(1, 1, 1) == mask(0, 0, mask_class(1, 1, 1)),
-              "three masks");
-
-template <int G, int SIGMA, int Q, int RHO, int NA>
-__device__ __forceinline__ uint32_t row_bits(const uint32_t (&Aw)[NA], const uint32_t (&Bw)[NA], const Masks &mk, uint32_t acc)
-{
-    constexpr int n0 = 12 * (6 * G + RHO) + 6 * Q;
-    const uint32_t f = SIGMA == 0 ? field<n0, 5>(Aw) : field<n0, 6>(Bw);
-    const uint32_t prod = __umul24(f, mult(SIGMA, Q, RHO % 3));
-    uint32_t d;
-    // (written out: the compiler regroups a chain of these into three ands and a v_or3_b32)
-    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(prod), "s"(mk.m[mask_class(SIGMA, Q, RHO % 3)]), "v"(acc));
-    return d;
-}
-
-// index bytes of carriers 3c + G, c = column(SIGMA, Q, b), in byte b
-template <int G, int SIGMA, int Q, int NA>
-__device__ __forceinline__ uint32_t group_word(const uint32_t (&Aw)[NA], const uint32_t (&Bw)[NA], const Masks &mk)
-{
-    uint32_t hi = row_bits<G, SIGMA, Q, 0>(Aw, Bw, mk, 0u);
-    hi = row_bits<G, SIGMA, Q, 1>(Aw, Bw, mk, hi);
-    hi = row_bits<G, SIGMA, Q, 2>(Aw, Bw, mk, hi);
-    uint32_t lo = row_bits<G, SIGMA, Q, 3>(Aw, Bw, mk, 0u);
-    lo = row_bits<G, SIGMA, Q, 4>(Aw, Bw, mk, lo);
-    lo = row_bits<G, SIGMA, Q, 5>(Aw, Bw, mk, lo);
-    return (hi << 3) | lo;
-}
-
-// where the index byte of data carrier m lies: word 4g + 2 sigma + q of the twelve, byte b
-constexpr int word_of(int m) { return 4 * (m % 3) + 2 * ((m / 3) & 1) + (m / 3) / 8; }
-constexpr int byte_of(int m) { return 3 - ((m / 3) % 8) / 2; }
-
 // v_perm_b32 selector that moves into slot word WORD the bytes it takes from carrier word SRC and
 // keeps the others (selector bytes 0-3: the word so far, 4-7: the carrier word); 0 if it takes none
 template <int WORD, int SRC>
@@ -767,25 +850,8 @@ template <int NA, int... WORD>
 __device__ __forceinline__ void slot_words(uint32_t (&Aw)[NA], uint32_t (&Bw)[NA], uint32_t neg, uint32_t *dst,
                                            std::integer_sequence<int, WORD...>)
 {
-    static_assert(NA == 7, "216 stream bits");
-    // (the empty asm keeps the compiler from folding the clearing into every field extract,
-    // which would turn each one-instruction bit-field extract into a shift and an and)
-#pragma unroll
-    for (int i = 0; i < NA; i++) {
-        Aw[i] &= keep_mask(0, i);
-        Bw[i] &= keep_mask(1, i);
-        asm volatile("" : "+v"(Aw[i]), "+v"(Bw[i]));
-    }
-    Masks mk = {{mask(0, 0, 0), mask(0, 0, 1), mask(0, 0, 2)}};
-    asm volatile("" : "+s"(mk.m[0]), "+s"(mk.m[1]), "+s"(mk.m[2]));
     uint32_t cw[12];
-#define R8_GROUP(G_)                                                                              \
-    cw[4 * G_ + 0] = group_word<G_, 0, 0>(Aw, Bw, mk); __builtin_amdgcn_sched_barrier(0);         \
-    cw[4 * G_ + 1] = group_word<G_, 0, 1>(Aw, Bw, mk); __builtin_amdgcn_sched_barrier(0);         \
-    cw[4 * G_ + 2] = group_word<G_, 1, 0>(Aw, Bw, mk); __builtin_amdgcn_sched_barrier(0);         \
-    cw[4 * G_ + 3] = group_word<G_, 1, 1>(Aw, Bw, mk); __builtin_amdgcn_sched_barrier(0);
-    R8_GROUP(0) R8_GROUP(1) R8_GROUP(2)
-#undef R8_GROUP
+    carrier_words(Aw, Bw, cw);
     ((dst[WORD] = slot_word<WORD>(cw, neg, std::make_integer_sequence<int, 12>{})), ...);
 }
 }   // namespace r8
@@ -853,17 +919,17 @@ __device__ __forceinline__ void message_slots(const uint32_t *MW, uint32_t *SI, 
 }
 
 constexpr int ENC_WAVES = 4;
-constexpr int ENC_A_WORDS = 1600;   // natural MPDU (2 zero words + <= 792 words), later the message words
-constexpr int ENC_U_WORDS = MAX_PLCP / 4 + 4;
 
 template <bool UNIFORM, int REGIME>
 __global__ void __launch_bounds__(64 * ENC_WAVES)
 k_encode_bits(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads,
               uint8_t *__restrict__ plcp_out, uint8_t *__restrict__ scr_out,
-              uint8_t *__restrict__ cod_out, uint8_t *__restrict__ itl_out)
+              uint8_t *__restrict__ cod_out, uint8_t *__restrict__ itl_out, uint32_t a_words, uint32_t u_words)
 {
-    __shared__ __align__(16) uint32_t s_a[ENC_WAVES][ENC_A_WORDS];
-    __shared__ __align__(16) uint32_t s_u[ENC_WAVES][ENC_U_WORDS];
+    // per wave: a_words for the natural-order MPDU, later the message words; u_words for the scrambled
+    // words -- both sized by the launcher for the plan's longest packet, so that batches of ordinary
+    // packets leave room for more workgroups per CU than the longest packet would
+    extern __shared__ __align__(16) uint32_t s_enc[];
     __shared__ uint32_t s_crc[CRC_TAB_WORDS];
     __shared__ uint32_t s_scr[SCR_TAB_WORDS];
 
@@ -871,8 +937,8 @@ k_encode_bits(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads,
     fill_scramble_tables(T, s_crc, s_scr, tid, 64 * ENC_WAVES);
     __syncthreads();
 
-    uint32_t *A = s_a[wave];
-    uint32_t *U = s_u[wave];
+    uint32_t *A = s_enc + (size_t)wave * (a_words + u_words);
+    uint32_t *U = A + a_words;
 
     // ragged plans: packets are drawn from the plan's second work counter (their cost follows
     // their length); uniform plans use a fixed stride
@@ -889,11 +955,23 @@ k_encode_bits(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads,
             return v;
         }
     };
+    // uniform plans: the next packet's payload is requested as soon as this one's is in LDS
+    [[maybe_unused]] PayloadAhead<8> ahead;
+    if constexpr (UNIFORM) {
+        const uint32_t p0 = next_packet(0, true);
+        if (p0 < P.n_pkts) ahead.fetch(payloads + load_pkt<UNIFORM>(P, p0).pay_off, P.pay_len, lane);
+    }
     for (uint32_t p = next_packet(0, true); p < P.n_pkts; p = next_packet(p, false)) {
         const Pkt k = load_pkt<UNIFORM>(P, p);
         const RegimeInfo ri = regime_info(REGIME ? REGIME : (int)k.regime);
         const uint32_t msg_len = 6u + k.n_sym * ri.n_cbps / 8u;
-        encode_packet<REGIME>(k, ri, T, payloads, A, U, s_crc, s_scr, lane, plcp_out, scr_out, cod_out);
+        if constexpr (UNIFORM) {
+            const uint32_t pn = next_packet(p, false);
+            encode_packet<REGIME>(k, ri, T, payloads, A, U, s_crc, s_scr, lane, plcp_out, scr_out, cod_out, &ahead,
+                                  pn < P.n_pkts ? payloads + load_pkt<UNIFORM>(P, pn).pay_off : nullptr, P.pay_len);
+        } else {
+            encode_packet<REGIME>(k, ri, T, payloads, A, U, s_crc, s_scr, lane, plcp_out, scr_out, cod_out);
+        }
         uint32_t *OUTW = A;
 
         // ---- 6. message bytes = OUTW stream shifted by 16 bits (6 SIGNAL bytes lead)
@@ -2176,9 +2254,12 @@ int ofdmtx_encode_bits(ofdmtx_ctx *ctx, const ofdmtx_plan *pl, const uint8_t *d_
     if (int rc = ofdmtx_plan_claim(pl, st)) return rc;
     const PlanParams &pp = pl->pp;
     const DevTables tab = ctx->tables();
+    const uint32_t a_words = pl->tx_u_words > pl->tx_m_words ? pl->tx_u_words : pl->tx_m_words;
+    const uint32_t u_words = pl->tx_u_words;
+    const size_t lds = (size_t)ENC_WAVES * (a_words + u_words) * sizeof(uint32_t);
 #define LAUNCH_ENC(U_, R_)                                                                           \
-    hipLaunchKernelGGL((k_encode_bits<U_, R_>), dim3(grid), dim3(64 * ENC_WAVES), 0, st, pp, tab,    \
-                       d_payloads, d_plcp, d_scrambled, d_coded, d_interleaved)
+    hipLaunchKernelGGL((k_encode_bits<U_, R_>), dim3(grid), dim3(64 * ENC_WAVES), lds, st, pp, tab,  \
+                       d_payloads, d_plcp, d_scrambled, d_coded, d_interleaved, a_words, u_words)
     if (!pp.uniform) {
         LAUNCH_ENC(false, 0);
     } else {
