@@ -218,55 +218,90 @@ __device__ __forceinline__ void punctured_bits(const uint32_t (&Aw)[NA], const u
 }
 
 // --------------------------------------------------------------------------------------
-// 64-QAM rate 3/4 (regime 8): interleaving by multiplication instead of bit by bit.
+// Interleaving by multiplication instead of bit by bit (QPSK, 16-QAM and 64-QAM at rates 1/2 and 3/4:
+// regimes 3, 4, 5, 6 and 8).
 //
-// A symbol's streams A and B are 18 units of 12 bits; unit r holds the encoder outputs of 12
-// input bits, of which puncturing (pu:316-328) keeps A bits 0,1 and B bits 0,2 of every three:
-// 16 bits, the columns c = 0..15 of row r of the interleaver's 18 x 16 block (pu:241-253).  Row
-// r = 6g + 3h + i0 feeds bit 3h + i of the constellation index of carrier 3c + g, i = (i0 - c) mod 3
-// (second permutation, pu:267-273): the 48 index bytes of a symbol are the transposed block.
-// Half a unit of one stream (5 or 6 bits, four of them kept) times a constant with four bits set
-// puts each kept bit into a byte of its own, at the bit position the row has in that byte; the
-// other partial products fall between those places (checked at compile time for every value of
-// the field, with the dropped bits cleared beforehand).  Per group g of 16 carriers this gives
-// four words -- (stream, half) = columns {8q + s, 8q + s + 2, ..} -- built from 6 rows each with
-// a bit-field extract, a 24-bit multiply and an and-or per row: 216 + 12 operations for 288 index
-// bits (two per bit otherwise).  The fused kernel's slot words then gather their bytes with
-// v_perm_b32; the mapper message takes them column by column (message_words).
-namespace r8 {
-constexpr int src_bit(int sigma, int b) { return sigma == 0 ? (b < 2 ? b : b + 1) : (b == 0 ? 0 : b == 3 ? 5 : b + 1); }
-constexpr int column(int sigma, int q, int b) { return 8 * q + 2 * (3 - b) + sigma; }
-constexpr int byte_pos(int sigma, int q, int i0, int b) { return 2 - ((i0 - column(sigma, q, b)) % 3 + 3) % 3; }
-constexpr uint32_t mult(int sigma, int q, int i0)
-{
-    uint32_t k = 0;
-    for (int b = 0; b < 4; b++) k |= 1u << (8 * b + byte_pos(sigma, q, i0, b) - src_bit(sigma, b));
-    return k;
-}
-constexpr uint32_t mask(int sigma, int q, int i0)
-{
-    uint32_t m = 0;
-    for (int b = 0; b < 4; b++) m |= 1u << (8 * b + byte_pos(sigma, q, i0, b));
-    return m;
-}
-constexpr bool spread_ok(int sigma, int q, int i0)
-{
-    const int len = sigma == 0 ? 5 : 6;
-    uint32_t live = 0;
-    for (int b = 0; b < 4; b++) live |= 1u << src_bit(sigma, b);
-    if (mult(sigma, q, i0) >= (1u << 24)) return false;
-    for (uint32_t f = 0; f < (1u << len); f++) {
-        if (f & ~live) continue;
-        uint32_t want = 0;
-        for (int b = 0; b < 4; b++) want |= ((f >> src_bit(sigma, b)) & 1u) << (8 * b + byte_pos(sigma, q, i0, b));
-        if (((f * mult(sigma, q, i0)) & mask(sigma, q, i0)) != want) return false;
+// A symbol's streams A and B are R = 3 N_bpsc units of U bits (U = 8 at rate 1/2, 12 at rate 3/4); unit
+// r holds the encoder outputs of U input bits, of which puncturing keeps all (rate 1/2) or A bits 0,1
+// and B bits 0,2 of every three (pu:316-328): 16 bits, the columns c = 0..15 of row r of the
+// interleaver's R x 16 block (pu:241-253), even columns from A and odd ones from B.  With
+// s = max(N_bpsc / 2, 1), row r = N_bpsc g + s h + i0 feeds bit s h + i of the constellation index of
+// carrier 3c + g, i = (i0 - c) mod s (second permutation, pu:267-273): the 48 index bytes of a symbol
+// are the transposed block.  Half a unit of one stream (4 to 6 bits, four of them kept) times a
+// constant with four bits set puts each kept bit into a byte of its own, at the bit position the
+// row has in that byte; the other partial products fall between those places (checked at compile
+// time for every value of the field, with the dropped bits cleared beforehand).  Per group g of 16
+// carriers this gives four words -- (stream, half) = columns {8q + sigma, 8q + sigma + 2, ..} --
+// built from N_bpsc rows each with a bit-field extract, a 24-bit multiply and an and-or per row: for
+// 64-QAM 216 + 12 operations for 288 index bits (two per bit otherwise).  The fused kernel's slot words
+// then gather their bytes with v_perm_b32; the mapper message takes them column by column.
+namespace spread {
+template <int NB, int P>
+struct Geo {
+    static_assert((NB == 2 || NB == 4 || NB == 6) && (P == 0 || P == 1), "QPSK .. 64-QAM, rates 1/2 and 3/4");
+    static constexpr int S = NB / 2;                        // rows that rotate among themselves
+    static constexpr int U = P == 0 ? 8 : 12;               // stream bits per unit
+    static constexpr int NDBPS = 3 * NB * U;                // bits of a stream per symbol
+    static constexpr int NA = (NDBPS + 31) / 32;
+    static constexpr int NW = (48 * NB + 31) / 32;          // words of the symbol's interleaved bits
+    static constexpr int len(int sigma) { return P == 0 ? 4 : 5 + sigma; }     // bits of a field
+    // value bit of a field (bit 0 = its last stream bit) that feeds byte b of the word
+    static constexpr int src_bit(int sigma, int b)
+    {
+        return P == 0 ? b : sigma == 0 ? (b < 2 ? b : b + 1) : (b == 0 ? 0 : b == 3 ? 5 : b + 1);
     }
-    return true;
-}
-static_assert(spread_ok(0, 0, 0) && spread_ok(0, 0, 1) && spread_ok(0, 0, 2) && spread_ok(0, 1, 0) &&
-              spread_ok(0, 1, 1) && spread_ok(0, 1, 2) && spread_ok(1, 0, 0) && spread_ok(1, 0, 1) &&
-              spread_ok(1, 0, 2) && spread_ok(1, 1, 0) && spread_ok(1, 1, 1) && spread_ok(1, 1, 2),
-              "a partial product collides with a kept bit");
+    static constexpr int column(int sigma, int q, int b) { return 8 * q + 2 * (3 - b) + sigma; }
+    static constexpr int byte_pos(int sigma, int q, int i0, int b) { return S - 1 - ((i0 - column(sigma, q, b)) % S + S) % S; }
+    static constexpr uint32_t mult(int sigma, int q, int i0)
+    {
+        uint32_t k = 0;
+        for (int b = 0; b < 4; b++) k |= 1u << (8 * b + byte_pos(sigma, q, i0, b) - src_bit(sigma, b));
+        return k;
+    }
+    static constexpr uint32_t mask(int sigma, int q, int i0)
+    {
+        uint32_t m = 0;
+        for (int b = 0; b < 4; b++) m |= 1u << (8 * b + byte_pos(sigma, q, i0, b));
+        return m;
+    }
+    // the masks differ only by the rotation of the rows over the bytes: S of them
+    static constexpr int mask_class(int sigma, int q, int i0)
+    {
+        for (int k = 0; k < S; k++)
+            if (mask(sigma, q, i0) == mask(0, 0, k)) return k;
+        return -1;
+    }
+    static constexpr bool ok(int sigma, int q, int i0)
+    {
+        uint32_t live = 0;
+        for (int b = 0; b < 4; b++) live |= 1u << src_bit(sigma, b);
+        if (mult(sigma, q, i0) >= (1u << 24) || mask_class(sigma, q, i0) < 0) return false;
+        for (uint32_t f = 0; f < (1u << len(sigma)); f++) {
+            if (f & ~live) continue;
+            uint32_t want = 0;
+            for (int b = 0; b < 4; b++) want |= ((f >> src_bit(sigma, b)) & 1u) << (8 * b + byte_pos(sigma, q, i0, b));
+            if (((f * mult(sigma, q, i0)) & mask(sigma, q, i0)) != want) return false;
+        }
+        return true;
+    }
+    static constexpr bool all_ok()
+    {
+        for (int sigma = 0; sigma < 2; sigma++)
+            for (int q = 0; q < 2; q++)
+                for (int i0 = 0; i0 < S; i0++)
+                    if (!ok(sigma, q, i0)) return false;
+        return true;
+    }
+    static_assert(all_ok(), "a partial product collides with a kept bit");
+    // stream bits that puncturing drops, cleared: at rate 3/4 A keeps n % 3 in {0, 1}, B keeps n % 3 in {0, 2}
+    static constexpr uint32_t keep_mask(int sigma, int word)
+    {
+        uint32_t m = 0;
+        for (int j = 0; j < 32; j++)
+            if (P == 0 || (32 * word + j) % 3 != (sigma == 0 ? 2 : 1)) m |= 1u << (31 - j);
+        return m;
+    }
+};
 
 // bits n0 .. n0 + LEN - 1 of a stream held as MSB-first words, right-aligned
 template <int N0, int LEN, int NA>
@@ -279,46 +314,41 @@ __device__ __forceinline__ uint32_t field(const uint32_t (&W)[NA])
         return __funnelshift_l(W[w + 1], W[w], o) >> (32 - LEN);
 }
 
-// stream bits that puncturing drops, cleared: A keeps n % 3 in {0, 1}, B keeps n % 3 in {0, 2}
-constexpr uint32_t keep_mask(int sigma, int word)
-{
-    uint32_t m = 0;
-    for (int j = 0; j < 32; j++)
-        if ((32 * word + j) % 3 != (sigma == 0 ? 2 : 1)) m |= 1u << (31 - j);
-    return m;
-}
-
-// one row's contribution to the word of (group G, stream SIGMA, half Q)
-// The three masks (one per rotation of the rows over the bytes), held in scalar registers so that
-// "(product & mask) | word so far" is one v_and_or_b32.
+// The masks, held in scalar registers so that "(product & mask) | word so far" is one v_and_or_b32.
 struct Masks { uint32_t m[3]; };
-constexpr int mask_class(int sigma, int q, int i0) { return mask(sigma, q, i0) == mask(0, 0, 0) ? 0 : mask(sigma, q, i0) == mask(0, 0, 1) ? 1 : 2; }
-static_assert(mask(0, 0, 2) != mask(0, 0, 0) && mask(0, 0, 2) != mask(0, 0, 1) && mask(1, 1, 1) == mask(0, 0, mask_class(1, 1, 1)),
-              "three masks");
 
-template <int G, int SIGMA, int Q, int RHO, int NA>
+// one row's contribution to the word of (group G, stream SIGMA, half Q), on top of acc
+template <int NB, int P, int G, int SIGMA, int Q, int RHO, int NA>
 __device__ __forceinline__ uint32_t row_bits(const uint32_t (&Aw)[NA], const uint32_t (&Bw)[NA], const Masks &mk, uint32_t acc)
 {
-    constexpr int n0 = 12 * (6 * G + RHO) + 6 * Q;
-    const uint32_t f = SIGMA == 0 ? field<n0, 5>(Aw) : field<n0, 6>(Bw);
-    const uint32_t prod = __umul24(f, mult(SIGMA, Q, RHO % 3));
+    using geo = Geo<NB, P>;
+    constexpr int n0 = geo::U * (NB * G + RHO) + (geo::U / 2) * Q;
+    const uint32_t f = SIGMA == 0 ? field<n0, geo::len(0)>(Aw) : field<n0, geo::len(1)>(Bw);
+    const uint32_t prod = __umul24(f, geo::mult(SIGMA, Q, RHO % geo::S));
     uint32_t d;
-    // (written out: the compiler regroups a chain of these into three ands and a v_or3_b32)
-    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(prod), "s"(mk.m[mask_class(SIGMA, Q, RHO % 3)]), "v"(acc));
+    // (written out: the compiler regroups a chain of these into ands and a v_or3_b32)
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(prod), "s"(mk.m[geo::mask_class(SIGMA, Q, RHO % geo::S)]), "v"(acc));
     return d;
 }
 
+// the rows RHO0 + I of one half (first index bits: RHO0 = 0, last: RHO0 = S)
+template <int NB, int P, int G, int SIGMA, int Q, int RHO0, int NA, int... I>
+__device__ __forceinline__ uint32_t half_word(const uint32_t (&Aw)[NA], const uint32_t (&Bw)[NA], const Masks &mk,
+                                              std::integer_sequence<int, I...>)
+{
+    uint32_t acc = 0;
+    ((acc = row_bits<NB, P, G, SIGMA, Q, RHO0 + I>(Aw, Bw, mk, acc)), ...);
+    return acc;
+}
+
 // index bytes of carriers 3c + G, c = column(SIGMA, Q, b), in byte b
-template <int G, int SIGMA, int Q, int NA>
+template <int NB, int P, int G, int SIGMA, int Q, int NA>
 __device__ __forceinline__ uint32_t group_word(const uint32_t (&Aw)[NA], const uint32_t (&Bw)[NA], const Masks &mk)
 {
-    uint32_t hi = row_bits<G, SIGMA, Q, 0>(Aw, Bw, mk, 0u);
-    hi = row_bits<G, SIGMA, Q, 1>(Aw, Bw, mk, hi);
-    hi = row_bits<G, SIGMA, Q, 2>(Aw, Bw, mk, hi);
-    uint32_t lo = row_bits<G, SIGMA, Q, 3>(Aw, Bw, mk, 0u);
-    lo = row_bits<G, SIGMA, Q, 4>(Aw, Bw, mk, lo);
-    lo = row_bits<G, SIGMA, Q, 5>(Aw, Bw, mk, lo);
-    return (hi << 3) | lo;
+    constexpr int S = Geo<NB, P>::S;
+    const uint32_t hi = half_word<NB, P, G, SIGMA, Q, 0>(Aw, Bw, mk, std::make_integer_sequence<int, S>{});
+    const uint32_t lo = half_word<NB, P, G, SIGMA, Q, S>(Aw, Bw, mk, std::make_integer_sequence<int, S>{});
+    return (hi << S) | lo;
 }
 
 // where the index byte of data carrier m lies: word 4g + 2 sigma + q of the twelve, byte b
@@ -327,53 +357,61 @@ constexpr int byte_of(int m) { return 3 - ((m / 3) % 8) / 2; }
 
 // The twelve words of a symbol: the index byte of carrier m in byte byte_of(m) of cw[word_of(m)].
 // Clears the dropped bits of Aw / Bw on the way.
-template <int NA>
+template <int NB, int P, int NA>
 __device__ __forceinline__ void carrier_words(uint32_t (&Aw)[NA], uint32_t (&Bw)[NA], uint32_t (&cw)[12])
 {
-    static_assert(NA == 7, "216 stream bits");
-    // (the empty asm keeps the compiler from folding the clearing into every field extract,
-    // which would turn each one-instruction bit-field extract into a shift and an and)
+    using geo = Geo<NB, P>;
+    static_assert(NA == geo::NA, "stream words");
+    if constexpr (P != 0) {
+        // (the empty asm keeps the compiler from folding the clearing into every field extract,
+        // which would turn each one-instruction bit-field extract into a shift and an and)
 #pragma unroll
-    for (int i = 0; i < NA; i++) {
-        Aw[i] &= keep_mask(0, i);
-        Bw[i] &= keep_mask(1, i);
-        asm volatile("" : "+v"(Aw[i]), "+v"(Bw[i]));
+        for (int i = 0; i < NA; i++) {
+            Aw[i] &= geo::keep_mask(0, i);
+            Bw[i] &= geo::keep_mask(1, i);
+            asm volatile("" : "+v"(Aw[i]), "+v"(Bw[i]));
+        }
     }
-    Masks mk = {{mask(0, 0, 0), mask(0, 0, 1), mask(0, 0, 2)}};
+    Masks mk = {{geo::mask(0, 0, 0), geo::mask(0, 0, geo::S > 1 ? 1 : 0), geo::mask(0, 0, geo::S > 2 ? 2 : 0)}};
     asm volatile("" : "+s"(mk.m[0]), "+s"(mk.m[1]), "+s"(mk.m[2]));
-#define R8_GROUP(G_)                                                                              \
-    cw[4 * G_ + 0] = group_word<G_, 0, 0>(Aw, Bw, mk); __builtin_amdgcn_sched_barrier(0);         \
-    cw[4 * G_ + 1] = group_word<G_, 0, 1>(Aw, Bw, mk); __builtin_amdgcn_sched_barrier(0);         \
-    cw[4 * G_ + 2] = group_word<G_, 1, 0>(Aw, Bw, mk); __builtin_amdgcn_sched_barrier(0);         \
-    cw[4 * G_ + 3] = group_word<G_, 1, 1>(Aw, Bw, mk); __builtin_amdgcn_sched_barrier(0);
-    R8_GROUP(0) R8_GROUP(1) R8_GROUP(2)
-#undef R8_GROUP
+#define SPREAD_GROUP(G_)                                                                                  \
+    cw[4 * G_ + 0] = group_word<NB, P, G_, 0, 0>(Aw, Bw, mk); __builtin_amdgcn_sched_barrier(0);           \
+    cw[4 * G_ + 1] = group_word<NB, P, G_, 0, 1>(Aw, Bw, mk); __builtin_amdgcn_sched_barrier(0);           \
+    cw[4 * G_ + 2] = group_word<NB, P, G_, 1, 0>(Aw, Bw, mk); __builtin_amdgcn_sched_barrier(0);           \
+    cw[4 * G_ + 3] = group_word<NB, P, G_, 1, 1>(Aw, Bw, mk); __builtin_amdgcn_sched_barrier(0);
+    SPREAD_GROUP(0) SPREAD_GROUP(1) SPREAD_GROUP(2)
+#undef SPREAD_GROUP
 }
 
-// The symbol's 288 interleaved bits as nine MSB-first words: carrier m's six index bits are message
-// bits 6m .. 6m + 5 (ftw/ftw_ofdm_mapper.cc:262-275 reads them MSB first), i.e. column c of the block
-// contributes 18 bits -- carriers 3c, 3c + 1, 3c + 2 -- at bit 18c.
-template <int C>
-__device__ __forceinline__ void put_column(const uint32_t (&cw)[12], uint32_t (&out)[9])
+// The symbol's interleaved bits as MSB-first words: carrier m's index bits are message bits
+// N_bpsc m .. (ftw/ftw_ofdm_mapper.cc:262-275 reads them MSB first), i.e. column c of the block
+// contributes 3 N_bpsc bits -- carriers 3c, 3c + 1, 3c + 2 -- at bit 3 N_bpsc c.
+template <int NB, int C, int NW>
+__device__ __forceinline__ void put_column(const uint32_t (&cw)[12], uint32_t (&out)[NW])
 {
     constexpr int w = word_of(3 * C) & 3, sh = 8 * byte_of(3 * C);      // the same place in each group's four words
-    const uint32_t v = (((cw[w] >> sh) & 63u) << 12) | (((cw[4 + w] >> sh) & 63u) << 6) | ((cw[8 + w] >> sh) & 63u);
-    constexpr int pos = 18 * C, k = pos >> 5, o = pos & 31;             // 18 bits from bit o of word k on
-    if constexpr (o + 18 <= 32) {
-        out[k] |= v << (32 - 18 - o);
+    constexpr uint32_t m = (1u << NB) - 1u;
+    const uint32_t v = (((cw[w] >> sh) & m) << (2 * NB)) | (((cw[4 + w] >> sh) & m) << NB) | ((cw[8 + w] >> sh) & m);
+    constexpr int bits = 3 * NB, pos = bits * C, k = pos >> 5, o = pos & 31;   // `bits` bits from bit o of word k on
+    if constexpr (o + bits <= 32) {
+        out[k] |= v << (32 - bits - o);
     } else {
-        out[k] |= v >> (o + 18 - 32);
-        out[k + 1] |= v << (64 - 18 - o);
+        out[k] |= v >> (o + bits - 32);
+        out[k + 1] |= v << (64 - bits - o);
     }
 }
-template <int... C>
-__device__ __forceinline__ void message_words(const uint32_t (&cw)[12], uint32_t (&out)[9], std::integer_sequence<int, C...>)
+template <int NB, int NW, int... C>
+__device__ __forceinline__ void message_words(const uint32_t (&cw)[12], uint32_t (&out)[NW], std::integer_sequence<int, C...>)
 {
 #pragma unroll
-    for (int i = 0; i < 9; i++) out[i] = 0;
-    (put_column<C>(cw, out), ...);
+    for (int i = 0; i < NW; i++) out[i] = 0;
+    (put_column<NB, C>(cw, out), ...);
 }
-}   // namespace r8
+
+// regimes this form covers
+constexpr bool covers(int nbpsc, int punct) { return (nbpsc == 2 || nbpsc == 4 || nbpsc == 6) && (punct == 0 || punct == 1); }
+}   // namespace spread
+
 
 // DATA symbols of one packet, one lane per symbol.  OUTW: MSB-first words, word 2 holds the
 // first 32 interleaved DATA bits (words 0,1 carry the SIGNAL symbol).
@@ -428,10 +466,10 @@ __device__ __forceinline__ void encode_data_symbols(const uint32_t *U, uint32_t 
         }
 
         uint32_t out[NW];
-        if constexpr (NBPSC == 6 && PUNCT == 1) {
+        if constexpr (spread::covers(NBPSC, PUNCT)) {
             uint32_t cw[12];
-            r8::carrier_words(Aw, Bw, cw);
-            r8::message_words(cw, out, std::make_integer_sequence<int, 16>{});
+            spread::carrier_words<NBPSC, PUNCT>(Aw, Bw, cw);
+            spread::message_words<NBPSC>(cw, out, std::make_integer_sequence<int, 16>{});
         } else {
             interleave_bits<NBPSC, PUNCT>(Aw, Bw, out, std::make_integer_sequence<int, NW>{});
         }
@@ -808,8 +846,8 @@ __device__ __forceinline__ void slot_words(const uint32_t (&Aw)[NA], const uint3
 }
 
 
-// The fused kernel's slot rows of a 64-QAM r3/4 symbol from its twelve carrier words.
-namespace r8 {
+// The fused kernel's slot rows of a symbol from its twelve carrier words.
+namespace spread {
 // v_perm_b32 selector that moves into slot word WORD the bytes it takes from carrier word SRC and
 // keeps the others (selector bytes 0-3: the word so far, 4-7: the carrier word); 0 if it takes none
 template <int WORD, int SRC>
@@ -836,30 +874,32 @@ __device__ __forceinline__ void gather_from(uint32_t &v, const uint32_t (&cw)[12
     if constexpr (sel != 0u) v = __builtin_amdgcn_perm(cw[SRC], v, sel);
 }
 
-template <int WORD, int... SRC>
+template <int NB, int WORD, int... SRC>
 __device__ __forceinline__ uint32_t slot_word(const uint32_t (&cw)[12], uint32_t neg, std::integer_sequence<int, SRC...>)
 {
     uint32_t v = 0;
     (gather_from<WORD, SRC>(v, cw), ...);
-    v |= SlotConst<6, WORD>::value;
-    if constexpr (SlotConst<6, WORD>::flip != 0u) v ^= neg ? SlotConst<6, WORD>::flip : 0u;
+    v |= SlotConst<NB, WORD>::value;
+    if constexpr (SlotConst<NB, WORD>::flip != 0u) v ^= neg ? SlotConst<NB, WORD>::flip : 0u;
     return v;
 }
 
-template <int NA, int... WORD>
+template <int NB, int P, int NA, int... WORD>
 __device__ __forceinline__ void slot_words(uint32_t (&Aw)[NA], uint32_t (&Bw)[NA], uint32_t neg, uint32_t *dst,
                                            std::integer_sequence<int, WORD...>)
 {
     uint32_t cw[12];
-    carrier_words(Aw, Bw, cw);
-    ((dst[WORD] = slot_word<WORD>(cw, neg, std::make_integer_sequence<int, 12>{})), ...);
+    carrier_words<NB, P>(Aw, Bw, cw);
+    ((dst[WORD] = slot_word<NB, WORD>(cw, neg, std::make_integer_sequence<int, 12>{})), ...);
 }
-}   // namespace r8
+}   // namespace spread
 
 // Slot rows of the DATA symbols with 0-based index d0 + lane (the SIGNAL symbol is not handled here), one
 // lane per symbol, into the row SI points at + lane.  Encoder, puncturing and interleaver as in
 // encode_data_symbols; the pilot polarity of DATA symbol d is entry (pilot_base + 1 + d) % 127.
-template <int NBPSC, int PUNCT>
+// MUL: by multiplication where that form exists (spread::covers); the PNC instantiations of the
+// kernel, which dispatch every regime per packet and have no register to spare, keep the bit-by-bit form.
+template <int NBPSC, int PUNCT, bool MUL = true>
 __device__ __forceinline__ void symbol_slots(const uint32_t *U, uint32_t *SI, uint32_t d0, uint32_t n_sym,
                                              uint32_t pilot_base, uint64_t pneg_lo, uint64_t pneg_hi, int lane)
 {
@@ -889,8 +929,8 @@ __device__ __forceinline__ void symbol_slots(const uint32_t *U, uint32_t *SI, ui
             Bw[i] = common ^ y5 ^ y4;
         }
         const uint32_t neg = pilot_negative((pilot_base + 1u + d) % 127u, pneg_lo, pneg_hi);
-        if constexpr (NBPSC == 6 && PUNCT == 1)
-            r8::slot_words(Aw, Bw, neg, SI + SLOT_ROW_WORDS * lane, std::make_integer_sequence<int, SLOT_ROW_WORDS>{});
+        if constexpr (MUL && spread::covers(NBPSC, PUNCT))
+            spread::slot_words<NBPSC, PUNCT>(Aw, Bw, neg, SI + SLOT_ROW_WORDS * lane, std::make_integer_sequence<int, SLOT_ROW_WORDS>{});
         else
             slot_words<NBPSC, PUNCT>(Aw, Bw, neg, SI + SLOT_ROW_WORDS * lane, std::make_integer_sequence<int, SLOT_ROW_WORDS>{});
     }
@@ -1300,14 +1340,14 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ in, float2 *__restri
                 }
             } else {
                 switch (REGIME ? (uint32_t)REGIME : k.regime) {
-                case 1: symbol_slots<1, 0>(U, rows, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
-                case 2: symbol_slots<1, 1>(U, rows, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
-                case 3: symbol_slots<2, 0>(U, rows, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
-                case 4: symbol_slots<2, 1>(U, rows, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
-                case 5: symbol_slots<4, 0>(U, rows, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
-                case 6: symbol_slots<4, 1>(U, rows, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
-                case 7: symbol_slots<6, 2>(U, rows, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
-                default: symbol_slots<6, 1>(U, rows, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
+                case 1: symbol_slots<1, 0, !PNC>(U, rows, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
+                case 2: symbol_slots<1, 1, !PNC>(U, rows, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
+                case 3: symbol_slots<2, 0, !PNC>(U, rows, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
+                case 4: symbol_slots<2, 1, !PNC>(U, rows, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
+                case 5: symbol_slots<4, 0, !PNC>(U, rows, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
+                case 6: symbol_slots<4, 1, !PNC>(U, rows, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
+                case 7: symbol_slots<6, 2, !PNC>(U, rows, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
+                default: symbol_slots<6, 1, !PNC>(U, rows, d0, k.n_sym, k.pilot_base, pneg_lo, pneg_hi, lane); break;
                 }
             }
             if (PNC && pilots_fixed) {
