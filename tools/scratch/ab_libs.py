@@ -15,8 +15,9 @@ from ofdm_amd import _lib  # noqa: E402
 from ofdm_amd.batch import TxContext  # noqa: E402
 
 ctx = TxContext(0)
-n = 1_000_000
-plan = ctx.plan_uniform(n, 8, 1500)
+REGIME = int(os.environ.get("AB_REGIME", "8"))       # AB_REGIME / AB_PACKETS: another rate / batch size
+n = int(os.environ.get("AB_PACKETS", "1000000"))
+plan = ctx.plan_uniform(n, REGIME, 1500)
 out, ok = plan.alloc_iq_spread()
 plain = plan.alloc_iq()
 pay = torch.randint(0, 256, (n * 1500,), dtype=torch.uint8, device=ctx.device)
@@ -32,9 +33,9 @@ for path in sys.argv[1:]:
         fn.restype, fn.argtypes = res, args
     h, p = VP(), VP()
     assert lib.ofdmtx_create(0, C.byref(h)) == 0
-    assert lib.ofdmtx_plan_uniform(h, n, 8, 1500, 0, 4.0, _lib.PILOT_REF_STREAM, 0, _lib.F_PREAMBLE | _lib.F_ZEROGAP, 0.3, C.byref(p)) == 0
+    assert lib.ofdmtx_plan_uniform(h, n, REGIME, 1500, 0, 4.0, _lib.PILOT_REF_STREAM, 0, _lib.F_PREAMBLE | _lib.F_ZEROGAP, 0.3, C.byref(p)) == 0
     p0 = VP()
-    assert lib.ofdmtx_plan_uniform(h, n, 8, 1500, 0, 4.0, _lib.PILOT_REF_STREAM, 0, 0, 0.3, C.byref(p0)) == 0
+    assert lib.ofdmtx_plan_uniform(h, n, REGIME, 1500, 0, 4.0, _lib.PILOT_REF_STREAM, 0, 0, 0.3, C.byref(p0)) == 0
     variants.append((os.path.basename(path), lib, h, p, p0))
 st = VP(torch.cuda.current_stream(ctx.device).cuda_stream)
 
