@@ -55,6 +55,7 @@ __global__ void __launch_bounds__(512) k_pkt_ahead(float4 *__restrict__ out, con
         asm volatile("global_load_dword %0, %1, off offset:1024" : "=v"(r4) : "v"(q) : "memory");           \
         asm volatile("global_load_dword %0, %1, off offset:1280" : "=v"(r5) : "v"(q) : "memory"); } while (0)
     if (p < n_pkts) LOADS(p);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5) :: "memory");   // the first request: a full wait
     for (; p < n_pkts; p += stride) {
         asm volatile("s_waitcnt vmcnt(47)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5) :: "memory");
         const float acc = (float)(r0 ^ r1 ^ r2 ^ r3 ^ r4 ^ r5);
@@ -62,6 +63,37 @@ __global__ void __launch_bounds__(512) k_pkt_ahead(float4 *__restrict__ out, con
         float4 *dst = out + (size_t)p * 3000;
 #pragma unroll
         for (int c = 0; c < 46; c++) dst[c * 64 + lane] = make_float4(acc, 2.f, 3.f, (float)c);
+        if (lane < 56) dst[46 * 64 + lane] = make_float4(acc, 2.f, 3.f, 46.f);
+        else asm volatile("" ::: "memory");
+    }
+}
+
+// the NEXT packet's payload requested one load at a time between this packet's stores (a load after every
+// eighth store) instead of six loads in one burst; counted wait (the last load is followed by 6 stores)
+__global__ void __launch_bounds__(512) k_pkt_sprinkled(float4 *__restrict__ out, const uint32_t *__restrict__ pay, uint32_t n_pkts)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t stride = gridDim.x * 8;
+    uint32_t r0, r1, r2, r3, r4, r5;
+    uint32_t p = blockIdx.x * 8 + wave;
+    if (p < n_pkts) LOADS(p);
+    // (the registers the loads write must not be touched before the data is there: a full wait after the
+    //  first request; in the loop the last load is followed by seven stores)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5) :: "memory");
+    for (; p < n_pkts; p += stride) {
+        asm volatile("s_waitcnt vmcnt(6)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5) :: "memory");
+        const float acc = (float)(r0 ^ r1 ^ r2 ^ r3 ^ r4 ^ r5);
+        const uint32_t pn = p + stride < n_pkts ? p + stride : p;
+        const uint32_t *q = pay + (size_t)pn * 375 + lane;
+        float4 *dst = out + (size_t)p * 3000;
+#define ST8(c0) _Pragma("unroll") for (int c = c0; c < c0 + 8 && c < 46; c++) dst[c * 64 + lane] = make_float4(acc, 2.f, 3.f, (float)c); asm volatile("" ::: "memory")
+        ST8(0);  asm volatile("global_load_dword %0, %1, off" : "=v"(r0) : "v"(q) : "memory");
+        ST8(8);  asm volatile("global_load_dword %0, %1, off offset:256" : "=v"(r1) : "v"(q) : "memory");
+        ST8(16); asm volatile("global_load_dword %0, %1, off offset:512" : "=v"(r2) : "v"(q) : "memory");
+        ST8(24); asm volatile("global_load_dword %0, %1, off offset:768" : "=v"(r3) : "v"(q) : "memory");
+        ST8(32); asm volatile("global_load_dword %0, %1, off offset:1024" : "=v"(r4) : "v"(q) : "memory");
+        asm volatile("global_load_dword %0, %1, off offset:1280" : "=v"(r5) : "v"(q) : "memory");
+        ST8(40);
         if (lane < 56) dst[46 * 64 + lane] = make_float4(acc, 2.f, 3.f, 46.f);
         else asm volatile("" ::: "memory");
     }
@@ -157,7 +189,15 @@ int main(int argc, char **argv)
             CK(hipEventRecord(ev1));
             CK(hipEventSynchronize(ev1));
             CK(hipEventElapsedTime(&ms, ev0, ev1));
-            printf(" | four payloads per read %.3f ms\n", ms / 3);
+            printf(" | four payloads per read %.3f ms", ms / 3);
+            hipLaunchKernelGGL(k_pkt_sprinkled, dim3(512), dim3(512), 0, 0, (float4 *)bufs[b], pay, n);
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(ev0));
+            for (int r = 0; r < 3; r++) hipLaunchKernelGGL(k_pkt_sprinkled, dim3(512), dim3(512), 0, 0, (float4 *)bufs[b], pay, n);
+            CK(hipEventRecord(ev1));
+            CK(hipEventSynchronize(ev1));
+            CK(hipEventElapsedTime(&ms, ev0, ev1));
+            printf(" | next payload one load per 8 stores %.3f ms\n", ms / 3);
             fflush(stdout);
         }
     return 0;
