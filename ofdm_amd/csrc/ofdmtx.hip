@@ -960,8 +960,13 @@ __device__ __forceinline__ void message_slots(const uint32_t *MW, uint32_t *SI, 
 
 constexpr int ENC_WAVES = 4;
 
+// (The instantiation that dispatches the regime per packet is held to 128 VGPRs = 4 waves per SIMD: the
+//  bit table of 64-QAM r2/3 alone would take 200, which every packet of a mixed batch then paid for in
+//  occupancy; with the cap that table spills instead -- 1.59 -> 1.29 ms on a mixed-rate batch of 4 10^5
+//  packets.  The same cap on the uniform 64-QAM r2/3 instantiation, where every packet runs the table,
+//  doubles its time.)
 template <bool UNIFORM, int REGIME>
-__global__ void __launch_bounds__(64 * ENC_WAVES)
+__global__ void __launch_bounds__(64 * ENC_WAVES) __attribute__((amdgpu_waves_per_eu(REGIME == 0 ? 4 : 1)))
 k_encode_bits(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads,
               uint8_t *__restrict__ plcp_out, uint8_t *__restrict__ scr_out,
               uint8_t *__restrict__ cod_out, uint8_t *__restrict__ itl_out, uint32_t a_words, uint32_t u_words)
