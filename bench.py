@@ -8,10 +8,17 @@
 One "step" is one pass of the transmit chain over one batch of P synthetic packets per GPU,
 payloads already resident in HBM: by default the fused kernel k_tx (payload -> IQ, the mapper
 bits never leave the CU); --fused 0 times the two-kernel path (k_encode_bits writes the mapper
-messages, the message-input instantiation of k_tx turns them into IQ).  With N > 1
-(launched by torch.distributed.run, one rank per GPU) the batch is sharded by packet index:
-every rank processes its own P packets, there is no collective on the data path, and the
-reported value is all ranks' samples divided by the slowest rank's time (weak scaling).
+messages, the message-input instantiation of k_tx turns them into IQ).  With N > 1 there is one
+rank (process) per GPU and the batch is sharded by packet index: every rank processes its own P
+packets, there is no collective on the data path, and the reported value is all ranks' samples
+divided by the slowest rank's time (weak scaling).
+
+How the N ranks come to be: under a launcher (torch.distributed.run sets WORLD_SIZE / RANK /
+LOCAL_RANK / MASTER_*) this process IS one rank.  Started plainly as `python bench.py --gpus N`
+with N > 1 it starts the N ranks itself: the parent parses the arguments, imports nothing that
+could touch a GPU, starts N fresh children of this same file with the rank environment set
+(rendezvous on 127.0.0.1), relays rank 0's JSON line and exits with the first non-zero child
+status.  `--gpus 1` runs in this process.
 
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (k_tx; with --fused 0 its
 message-input instantiation) against the HBM peak from its algorithmic bytes and its launch time measured with
@@ -20,17 +27,28 @@ events on the launch stream; `cpu_baseline` times the plain-C oracle port on the
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from ofdm_amd import _lib  # noqa: E402
-from ofdm_amd.batch import TxContext  # noqa: E402
+# numpy, torch and the library binding are imported by load_runtime(), i.e. only in a process that is a
+# rank: the parent of a self-started multi-rank run must stay free of anything that initialises a GPU
+np = torch = _lib = TxContext = None
+
+
+def load_runtime():
+    global np, torch, _lib, TxContext
+    import numpy
+    import torch as torch_
+    from ofdm_amd import _lib as lib_
+    from ofdm_amd.batch import TxContext as ctx_
+    np, torch, _lib, TxContext = numpy, torch_, lib_, ctx_
+
 
 REGIME = 8            # 54 Mbit/s, 64-QAM r=3/4
 PAYLOAD = 1500
@@ -226,8 +244,9 @@ def run_rawofdm(a, ctx, dev, world, rank, dist, backend):
             events[2].record()
 
     dt, evs = timed_steps(step, a, dist, backend, dev)
+    kernel_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
+    by_rank = per_rank(kernel_ms, dist, backend, dev, world)
     if rank == 0:
-        kernel_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
         alg_bytes = data.numel() * 8 + plan.n_samples * 8          # carrier values read + rows written
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         print(json.dumps({
@@ -241,6 +260,7 @@ def run_rawofdm(a, ctx, dev, world, rank, dist, backend):
                        "parallelism": "frames sharded by index over %d GPU(s), no collective" % world},
             "iq_placement": placement,
             "kernel_ms": {"k_raw_modulate": kernel_ms},
+            "ranks": ranks_record(a, dist, backend, world, by_rank),
             "roofline": {"bound": "hbm", "kernel": "k_raw_modulate", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": alg_bytes}}), flush=True)
@@ -280,8 +300,9 @@ def run_ragged(a, ctx, dev, world, rank, dist, backend):
     samples = torch.tensor([plan.n_samples], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if dist:
         dist.all_reduce(samples)                       # shards differ in size: the job's samples per step
+    kernel_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
+    by_rank = per_rank(kernel_ms, dist, backend, dev, world)
     if rank == 0:
-        kernel_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
         alg_bytes = int(lens.sum()) + plan.n_samples * 8            # payloads read + rows written (rank 0's shard)
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         print(json.dumps({
@@ -295,14 +316,36 @@ def run_ragged(a, ctx, dev, world, rank, dist, backend):
                        "parallelism": "packet ranges per rank over %d GPU(s), pilot counter continued, no collective" % world},
             "iq_placement": placement,
             "kernel_ms": {"k_tx": kernel_ms},
+            "ranks": ranks_record(a, dist, backend, world, by_rank),
             "roofline": {"bound": "hbm", "kernel": "k_tx (ragged)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": alg_bytes}}), flush=True)
 
 
-def main():
+def per_rank(x, dist, backend, dev, world):
+    """x of every rank, in rank order (a list of floats on every rank)."""
+    if not dist:
+        return [float(x)]
+    t = torch.tensor([float(x)], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    parts = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(parts, t)
+    return [float(q.item()) for q in parts]
+
+
+def ranks_record(a, dist, backend, world, kernel_ms_by_rank):
+    """What lets a reader of the line see that N ranks ran: the process group's own size, how the ranks
+    were started and every rank's mean kernel time over the timed steps."""
+    return {"world_size": dist.get_world_size() if dist else 1, "backend": ("rccl" if backend == "nccl" else backend) if dist else None,
+            "gpus_requested": a.gpus,
+            "started_by": "single process" if world == 1 else (
+                "bench.py (one child process per rank)" if os.environ.get("BENCH_SELF_STARTED") else "external launcher"),
+            "kernel_ms_per_rank": [round(v, 4) for v in kernel_ms_by_rank]}
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="ranks = GPUs of this node; > 1 without a launcher's WORLD_SIZE: this process starts them")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--packets", type=int, default=1_000_000, help="packets per GPU per step")
@@ -325,9 +368,69 @@ def main():
     ap.add_argument("--gather", type=int, default=0,
                     help="1: every step also collects all shards' IQ on rank 0 (config 5: RCCL send/recv, chunk k in "
                          "flight under the kernels of chunk k + 1); --packets is cut so that N shards fit the root")
-    ap.add_argument("--gather-chunks", type=int, default=8, help="chunks a shard is produced and sent in")
-    a = ap.parse_args()
+    ap.add_argument("--gather-chunks", type=int, default=0,
+                    help="chunks a shard is produced and sent in; 0: chunks of about 12 288 packets (0.59 GB of IQ), whose "
+                         "k_tx launch ends within about 0.1 ms, so that the transfer kernels of the exchange are never "
+                         "parked behind a long-running persistent grid")
+    a = ap.parse_args(argv)
+    if a.gpus < 1:
+        ap.error("--gpus must be at least 1")
+    return a
 
+
+def start_ranks(n_ranks, argv):
+    """Parent of a self-started run: N fresh children of this file, one per GPU, each with the rank
+    environment a launcher would set.  Nothing here touches a GPU (no torch, no library), and no
+    process image is replaced.  Rank 0's JSON line is relayed on stdout; everything else the ranks print
+    goes to stderr.  Returns the exit status: 0 when every rank ended with 0, else the first failure's
+    (after which the remaining ranks are terminated by PID)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, WORLD_SIZE=str(n_ranks), RANK=str(r), LOCAL_RANK=str(r), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BENCH_SELF_STARTED="1")
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + list(argv), env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0) or None))
+
+    def relay():
+        # stdout carries the JSON line and nothing else; whatever a library prints besides it
+        # (gloo's connection notes, for one) goes to stderr
+        for line in procs[0].stdout:
+            dest = sys.stdout if line.startswith("{") else sys.stderr
+            dest.write(line)
+            dest.flush()
+
+    t = threading.Thread(target=relay, daemon=True)
+    t.start()
+    status = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad:
+            status = bad[0] if bad[0] > 0 else 128 - bad[0]
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            deadline = time.time() + 10
+            for p in procs:
+                try:
+                    p.wait(timeout=max(0.1, deadline - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            sys.stderr.write("bench.py: a rank ended with status %s; exit codes %s\n" % (bad[0], [p.poll() for p in procs]))
+            break
+        if all(c == 0 for c in codes):
+            break
+        time.sleep(0.1)
+    t.join(timeout=5)
+    return status
+
+
+def main(a):
+    load_runtime()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -335,8 +438,13 @@ def main():
     # BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks then
     # share devices); the real runs use RCCL ("nccl"), one rank per GPU
     backend = os.environ.get("BENCH_BACKEND", "nccl")
+    if world != a.gpus and rank == 0:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started %d rank(s); reporting n_gpus = %d\n" % (a.gpus, world, world))
     if backend != "nccl":
         local = local % max(torch.cuda.device_count(), 1)
+    elif local >= torch.cuda.device_count():
+        sys.exit("bench.py: rank %d needs GPU %d, this node shows %d (BENCH_BACKEND=gloo rehearses more ranks than GPUs)"
+                 % (rank, local, torch.cuda.device_count()))
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
@@ -374,7 +482,7 @@ def main():
                                      a.placement_candidates, bool(a.placement_compare))
     if gather:
         from ofdm_amd.dist import chunk_bounds, gather_chunked
-        spans = chunk_bounds(n, a.gather_chunks)
+        spans = chunk_bounds(n, a.gather_chunks if a.gather_chunks > 0 else max(1, -(-n // 12288)))
         chunk_plans = [ctx.plan_uniform(hi - lo, REGIME, PAYLOAD,
                                         pilot_start=(pilot_start + lo * (info.n_sym + 1)) % 127) for lo, hi in spans]
         gathered = torch.empty(world * plan.n_samples, dtype=torch.complex64, device=dev) if rank == 0 else None
@@ -407,6 +515,7 @@ def main():
 
     first_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
     second_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))
+    by_rank = per_rank(first_ms if (a.fused or gather) else second_ms, dist, backend, dev, world)
 
     # the two-kernel path, outside the timed region, for the per-stage numbers
     stage = None
@@ -471,6 +580,7 @@ def main():
                            world, "IQ gathered on rank 0 every step in %d overlapped chunks" % len(spans) if gather else "no collective")},
             "iq_placement": placement,
             "kernel_ms": kernels,
+            "ranks": ranks_record(a, dist, backend, world, by_rank),
             # spread of the dominant kernel over the timed steps (first, fastest, slowest)
             "kernel_ms_steps": {"first": float(evs[0][0].elapsed_time(evs[0][1])),
                                 "min": float(min(e[0].elapsed_time(e[1]) for e in evs)),
@@ -482,6 +592,16 @@ def main():
                                            "not collected during this run)",
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
+        if gather:
+            # what arrives at the root per step: every peer's shard, each over its own xGMI link
+            inbound = (world - 1) * n * info.n_rows * 640
+            link = 153.6                                            # GB/s per xGMI link and direction (spec)
+            out["gather"] = {"chunks": len(spans), "packets_per_chunk": spans[0][1] - spans[0][0],
+                             "root_inbound_GBps": inbound * a.steps / dt / 1e9,
+                             "root_inbound_bound_GBps": (world - 1) * link,
+                             "frac_of_bound": inbound * a.steps / dt / 1e9 / ((world - 1) * link),
+                             "note": "bound = one xGMI link per peer into the root (spec rate); a rehearsal over gloo "
+                                     "moves the shards through host memory and says nothing about the links"}
         if stage is not None:
             mb = n * (info.msg_len + info.n_rows * 640)
             # map + IFFT + CP stage on its own: mapper messages (2058 B/packet) -> IQ
@@ -501,4 +621,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(start_ranks(args.gpus, sys.argv[1:]))
+    main(args)

@@ -74,6 +74,17 @@ def gather_iq(iq, dst=0, group=None):
     return None
 
 
+_side_streams = {}
+
+
+def _side_stream(device):
+    """The copy / transfer stream of `device` for gather_chunked, created once per device."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
+
+
 def chunk_bounds(n_pkts, n_chunks):
     """Packet ranges [lo, hi) of the chunks a shard is produced and sent in (n_chunks >= 1, balanced)."""
     n_chunks = max(1, min(int(n_chunks), max(int(n_pkts), 1)))
@@ -109,7 +120,12 @@ def gather_chunked(produce, chunk_samples, dst=0, group=None, out=None, device=N
     sizes_all = [None] * world                           # every rank's chunk sizes (a few integers, once per call)
     dist.all_gather_object(sizes_all, sizes_local, group=group)
     compute = torch.cuda.current_stream(device) if gpu else None
-    side = torch.cuda.Stream(device=device) if gpu else None
+    side = _side_stream(device) if gpu else None
+    if gpu:
+        # whatever the compute stream still does with `out` or with recycled memory (a consumer of the
+        # previous call's result, kernels of a tensor the caching allocator has just handed back) comes
+        # first: nothing is received or sent from the side stream before it
+        side.wait_stream(compute)
 
     def host_buffer(n_floats):
         return torch.empty(n_floats, dtype=torch.float32, pin_memory=gpu)
