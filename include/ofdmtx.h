@@ -56,6 +56,16 @@ extern "C" {
  * of the two; the zero gap is the same 13 rows (ftw/ftw_pnc_zerogap.cc:88-92). */
 #define OFDMTX_F_PNC_A 8u
 #define OFDMTX_F_PNC_B 16u
+/* The plan's "payload" of every packet is the whole PSDU -- MPDU and FCS as they go on air, bytes in
+ * natural order (the first byte's least significant bit is sent first) -- instead of the body behind
+ * the MAC header of examples/ftw_packet_utils.py:28-36: no header is built and no CRC computed, and
+ * payload_len (0..3168) is the SIGNAL field's LENGTH.  Everything else (SIGNAL, SERVICE, scrambler,
+ * tail, pad, encoder, ...) is the same code.  The reference's Python cannot send such a frame (its
+ * header and FCS are fixed, :28-36,370-372); its MATLAB model can (matlab/encode.m:55-66 takes any MPDU,
+ * :221-223 forces the FCS printed in the standard), and this flag is what lets the Annex G.8 frame of
+ * matlab/802.11-2007-Annex-G.8.txt run through ofdmtx_tx / ofdmtx_encode_bits.  Not with a PNC role or
+ * PNC pilots (OFDMTX_EINVAL).  ofdmtx_rx_decode returns the whole PSDU for such a plan. */
+#define OFDMTX_F_RAW_PSDU 32u
 
 /* pilot polarity index of symbol s of packet q */
 #define OFDMTX_PILOT_REF_STREAM 0 /* running counter over the whole stream, as the reference's

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("OFDMTX_LIB", os.path.join(_HERE, "libofdmtx.so"))
 
 OK = 0
 EINVAL, EREGIME, ELENGTH, EHIP, ENOMEM, ESHAPE, ETOOBIG, EBUSY, ECOMM = -1, -2, -3, -4, -5, -6, -7, -8, -9
-F_PREAMBLE, F_ZEROGAP, F_SWAPIQ, F_PNC_A, F_PNC_B = 1, 2, 4, 8, 16
+F_PREAMBLE, F_ZEROGAP, F_SWAPIQ, F_PNC_A, F_PNC_B, F_RAW_PSDU = 1, 2, 4, 8, 16, 32
 PILOT_REF_STREAM, PILOT_PER_PACKET, PILOT_PNC_A, PILOT_PNC_B, PILOT_PNC_ALL = 0, 1, 2, 3, 4
 # status bits of the loop-back verifier (ofdmtx_rx_demod / ofdmtx_rx_decode)
 RX_PILOTS, RX_NULLS, RX_SIGNAL, RX_LENGTH, RX_SERVICE, RX_TAIL, RX_FCS, RX_CODE = 1, 2, 4, 8, 16, 32, 64, 128

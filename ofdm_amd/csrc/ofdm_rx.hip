@@ -192,7 +192,12 @@ k_rx_decode(PlanParams P, DevTables T, const uint8_t *__restrict__ coded, uint8_
     uint32_t length = 0;
     for (int i = 0; i < 12; i++) length |= ((sig >> (18 - i)) & 1u) << i;
     if (rate != (uint32_t)ri.rate_bits || ((sig >> 19) & 1u) || (__popc(sig >> 6) & 1u) || (sig & 0x3Fu)) bad |= OFDMTX_RX_SIGNAL;
-    const uint32_t want_len = 24u + k.pay_len + 4u;       // MAC header + payload + FCS (pu:28-36,193)
+    // MAC header + payload + FCS (pu:28-36,193); a raw-PSDU plan's bytes are the whole PSDU, which
+    // comes back whole (FCS included; without one -- fewer than four bytes -- nothing is checked)
+    const bool raw = (P.flags & OFDMTX_F_RAW_PSDU) != 0;
+    const uint32_t hdr = raw ? 0u : 24u;
+    const uint32_t want_len = raw ? k.pay_len : 24u + k.pay_len + 4u;
+    const uint32_t fcs_at = want_len >= 4u ? want_len - 4u : want_len;   // first FCS byte
     if (length != want_len) bad |= OFDMTX_RX_LENGTH;
 
     // ---- DATA: SERVICE (16 bits), PSDU, six tail bits, pad (17.3.5)
@@ -217,20 +222,20 @@ k_rx_decode(PlanParams P, DevTables T, const uint8_t *__restrict__ coded, uint8_
         } else if (n < psdu_end) {
             const uint32_t q = n - 16u, bi = q & 7u, by = q >> 3;
             byte |= bit << bi;                            // 17.3.5.1: LSB first
-            if (by + 4u < want_len) {
+            if (by < fcs_at) {
                 crc = (crc >> 1) ^ (0xEDB88320u & (0u - ((crc ^ bit) & 1u)));
             } else {
-                fcs |= bit << (q - 8u * (want_len - 4u));
+                fcs |= bit << (q - 8u * fcs_at);
             }
             if (bi == 7u) {
-                if (by >= 24u && by + 4u < want_len) pay[by - 24u] = (uint8_t)byte;
+                if (by >= hdr && (raw || by < fcs_at)) pay[by - hdr] = (uint8_t)byte;
                 byte = 0;
             }
         } else if (n < psdu_end + 6u) {
             if (scr) bad |= OFDMTX_RX_TAIL;               // tail bits are zero AFTER scrambling (17.3.5.2)
         }
     }
-    if ((crc ^ 0xFFFFFFFFu) != fcs) bad |= OFDMTX_RX_FCS;
+    if (fcs_at != want_len && (crc ^ 0xFFFFFFFFu) != fcs) bad |= OFDMTX_RX_FCS;
     if (mism) bad |= OFDMTX_RX_CODE;
     status[p] |= bad;
 }

@@ -509,7 +509,10 @@ struct PayloadAhead {
 
 // AHEAD: `ahead` holds the first round of this packet's payload words on entry; once they are in
 // LDS the first round of the packet whose payload starts at next_pp (nullptr: none) is requested.
-template <int K, bool AHEAD = false>
+// RAW (plans with OFDMTX_F_RAW_PSDU): the packet's bytes are the whole PSDU -- MPDU and FCS as they go
+// on air, in natural byte order -- so no MAC header is built and no CRC computed; LENGTH is the byte
+// count itself.  Everything behind step 2 is the same code.
+template <int K, bool AHEAD = false, bool RAW = false>
 __device__ __forceinline__ void scramble_packet(const Pkt &k, const RegimeInfo &ri, const DevTables &T,
                                                 const uint8_t *__restrict__ payloads, uint32_t *A, uint32_t *U,
                                                 const uint32_t *s_crc, const uint32_t *s_scr, int lane_in,
@@ -521,12 +524,14 @@ __device__ __forceinline__ void scramble_packet(const Pkt &k, const RegimeInfo &
     // encoder needs and come back as scratch reloads, which wait for every store in flight.
     int lane = lane_in;
     asm volatile("" : "+v"(lane));
-    const uint32_t mpdu_len = 24u + k.pay_len;
-    const uint32_t length = mpdu_len + 4u;                                   // pu:193
-    const uint32_t n_pad = k.n_sym * ri.n_dbps - (54u + 8u * mpdu_len);      // pu:97
+    const uint32_t mpdu_len = RAW ? 0u : 24u + k.pay_len;
+    const uint32_t length = RAW ? k.pay_len : mpdu_len + 4u;                 // pu:193
+    const uint32_t n_pad = RAW ? k.n_sym * ri.n_dbps - (22u + 8u * length)
+                               : k.n_sym * ri.n_dbps - (54u + 8u * mpdu_len);   // pu:97
     const uint32_t plcp_len = 5u + length + (n_pad + 13u) / 8u;              // pu:160-171
     const uint32_t n_words = (plcp_len + 3u) / 4u;                           // stream words
-    const uint32_t n_dw = (mpdu_len + 3u) / 4u;                              // MPDU dwords
+    const uint32_t n_dw = RAW ? (length + 3u) / 4u : (mpdu_len + 3u) / 4u;   // MPDU (RAW: PSDU) dwords
+    constexpr uint32_t HDR = RAW ? 2u : 8u;                                  // words in front of the caller's bytes
 
     SEC("e1_stage");
     // ---- 1. MPDU in natural byte order (pu:28-36,100), Dw[-2], Dw[-1] and the tail zero
@@ -535,18 +540,20 @@ __device__ __forceinline__ void scramble_packet(const Pkt &k, const RegimeInfo &
         // A[0] byte 3 and A[1] = the SIGNAL field and the SERVICE bits (0, pu:183), every byte with its
         // bits reversed like the MPDU's, so that step 3 treats the whole PLCP stream alike;
         // A[2..7] = MAC header; A[8 + j] = payload dword j; zeros up to A[n_words + 2]
-        if (lane < 8) {
+        if (lane < (int)HDR) {
             const uint32_t rev = __brev(length) >> 20;                           // pu:147-150
             const uint32_t par = (__popc(rev & 0xFFFu) + __popc((uint32_t)ri.rate_bits)) & 1u;   // pu:153-157
             const uint32_t field = ((uint32_t)ri.rate_bits << 20) | ((rev & 0xFFFu) << 7) | (par << 6);   // pu:174-180
             const uint32_t sig = __brev(field) >> 8;                             // stream word 0 = __brev(sig)
             uint32_t v = lane == 0 ? sig << 24 : sig >> 8;
-            v = lane == 2 ? (0x00000008u | ((k.txtime >> 8) & 0xFFu) << 16 | (k.txtime & 0xFFu) << 24) : v;   // pu:91
-            v = lane == 3 ? 0xcd086000u : v;
-            v = lane == 4 ? 0x2000a637u : v;
-            v = lane == 5 ? 0xf13c01d6u : v;
-            v = lane == 6 ? 0xad086000u : v;
-            v = lane == 7 ? 0x0000af3bu : v;
+            if constexpr (!RAW) {
+                v = lane == 2 ? (0x00000008u | ((k.txtime >> 8) & 0xFFu) << 16 | (k.txtime & 0xFFu) << 24) : v;   // pu:91
+                v = lane == 3 ? 0xcd086000u : v;
+                v = lane == 4 ? 0x2000a637u : v;
+                v = lane == 5 ? 0xf13c01d6u : v;
+                v = lane == 6 ? 0xad086000u : v;
+                v = lane == 7 ? 0x0000af3bu : v;
+            }
             A[lane] = v;
         }
         // The payload may start at any byte: aligned dwords q[j], q[j + 1] are funnelled together.
@@ -555,8 +562,8 @@ __device__ __forceinline__ void scramble_packet(const Pkt &k, const RegimeInfo &
         const uint8_t *pp = payloads + k.pay_off;
         const uint32_t al = (uint32_t)(reinterpret_cast<uintptr_t>(pp) & 3u);
         const uint32_t *q = reinterpret_cast<const uint32_t *>(pp - al);
-        const uint32_t n_pw = n_dw - 6u;                                     // payload dwords, the last may be partial
-        const uint32_t total = n_words + 3u - 8u;                            // words behind the header to write
+        const uint32_t n_pw = n_dw - (HDR - 2u);                             // payload dwords, the last may be partial
+        const uint32_t total = n_words + 3u - HDR;                           // words behind the header to write
         for (uint32_t j0 = (uint32_t)lane; j0 < total; j0 += 64u * K) {
             uint32_t lo[K], hi[K];
 #pragma unroll
@@ -580,7 +587,7 @@ __device__ __forceinline__ void scramble_packet(const Pkt &k, const RegimeInfo &
                     uint32_t v = al ? (uint32_t)((((uint64_t)hi[kk] << 32) | lo[kk]) >> (8u * al)) : lo[kk];
                     const uint32_t nb = k.pay_len - 4u * j;                  // bytes left from this word on
                     if (j < n_pw && nb < 4u) v &= (1u << (8u * nb)) - 1u;
-                    A[8u + j] = j < n_pw ? v : 0u;
+                    A[HDR + j] = j < n_pw ? v : 0u;
                 }
             }
         }
@@ -590,8 +597,8 @@ __device__ __forceinline__ void scramble_packet(const Pkt &k, const RegimeInfo &
     wave_sync();
 
     SEC("e2_crc");
-    // ---- 2. CRC-32 of the MPDU (ftw/ftw_crc32.cc:52-57)
-    {
+    // ---- 2. CRC-32 of the MPDU (ftw/ftw_crc32.cc:52-57); a raw PSDU brings its FCS along
+    if constexpr (!RAW) {
         const uint32_t c4 = (n_dw + 63u) / 64u;
         const uint32_t j0 = lane * c4;
         uint32_t st = lane == 0 ? 0xFFFFFFFFu : 0u;
@@ -654,14 +661,15 @@ __device__ __forceinline__ void scramble_packet(const Pkt &k, const RegimeInfo &
 // words of LDS (first the natural-order MPDU, finally the message words OUTW: OUTW[0] low half
 // and OUTW[1] = the 48 SIGNAL bits, OUTW[2..] = interleaved DATA bits, all MSB first);
 // U: >= n_words + 2 words.  plcp_out / scr_out / cod_out are optional taps (global memory).
-template <int REGIME>
+template <int REGIME, bool RAW = false>
 __device__ __forceinline__ void encode_packet(const Pkt &k, const RegimeInfo &ri, const DevTables &T,
                                      const uint8_t *__restrict__ payloads, uint32_t *A, uint32_t *U,
                                      const uint32_t *s_crc, const uint32_t *s_scr, int lane,
                                      uint8_t *plcp_out, uint8_t *scr_out, uint8_t *cod_out,
                                      PayloadAhead<8> *ahead = nullptr, const uint8_t *next_pp = nullptr, uint32_t next_len = 0)
 {
-    if (ahead) scramble_packet<8, true>(k, ri, T, payloads, A, U, s_crc, s_scr, lane, plcp_out, scr_out, ahead, next_pp, next_len);
+    if constexpr (RAW) scramble_packet<8, false, true>(k, ri, T, payloads, A, U, s_crc, s_scr, lane, plcp_out, scr_out);
+    else if (ahead) scramble_packet<8, true>(k, ri, T, payloads, A, U, s_crc, s_scr, lane, plcp_out, scr_out, ahead, next_pp, next_len);
     else scramble_packet<8>(k, ri, T, payloads, A, U, s_crc, s_scr, lane, plcp_out, scr_out);
 
     SEC("e4_signal");
@@ -965,7 +973,8 @@ constexpr int ENC_WAVES = 4;
 //  occupancy; with the cap that table spills instead -- 1.59 -> 1.29 ms on a mixed-rate batch of 4 10^5
 //  packets.  The same cap on the uniform 64-QAM r2/3 instantiation, where every packet runs the table,
 //  doubles its time.)
-template <bool UNIFORM, int REGIME>
+//  RAW: the instantiations for plans with OFDMTX_F_RAW_PSDU (regime dispatched per packet).
+template <bool UNIFORM, int REGIME, bool RAW = false>
 __global__ void __launch_bounds__(64 * ENC_WAVES) __attribute__((amdgpu_waves_per_eu(REGIME == 0 ? 4 : 1)))
 k_encode_bits(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads,
               uint8_t *__restrict__ plcp_out, uint8_t *__restrict__ scr_out,
@@ -1002,7 +1011,7 @@ k_encode_bits(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads,
     };
     // uniform plans: the next packet's payload is requested as soon as this one's is in LDS
     [[maybe_unused]] PayloadAhead<8> ahead;
-    if constexpr (UNIFORM) {
+    if constexpr (UNIFORM && !RAW) {
         const uint32_t p0 = next_packet(0, true);
         if (p0 < P.n_pkts) ahead.fetch(payloads + load_pkt<UNIFORM>(P, p0).pay_off, P.pay_len, lane);
     }
@@ -1010,12 +1019,12 @@ k_encode_bits(PlanParams P, DevTables T, const uint8_t *__restrict__ payloads,
         const Pkt k = load_pkt<UNIFORM>(P, p);
         const RegimeInfo ri = regime_info(REGIME ? REGIME : (int)k.regime);
         const uint32_t msg_len = 6u + k.n_sym * ri.n_cbps / 8u;
-        if constexpr (UNIFORM) {
+        if constexpr (UNIFORM && !RAW) {
             const uint32_t pn = next_packet(p, false);
             encode_packet<REGIME>(k, ri, T, payloads, A, U, s_crc, s_scr, lane, plcp_out, scr_out, cod_out, &ahead,
                                   pn < P.n_pkts ? payloads + load_pkt<UNIFORM>(P, pn).pay_off : nullptr, P.pay_len);
         } else {
-            encode_packet<REGIME>(k, ri, T, payloads, A, U, s_crc, s_scr, lane, plcp_out, scr_out, cod_out);
+            encode_packet<REGIME, RAW>(k, ri, T, payloads, A, U, s_crc, s_scr, lane, plcp_out, scr_out, cod_out);
         }
         uint32_t *OUTW = A;
 
@@ -1135,7 +1144,10 @@ constexpr int TX_B_WORDS = 8 * RS * 2;
 // PNC: the instantiations for plans with a PNC role (six-row preamble patterns, constant pilots).
 // They are separate so that the standard ones keep their register allocation; they dispatch
 // the regime per packet (REGIME = 0).
-template <bool UNIFORM, int REGIME, bool FROM_MSG, bool PNC = false>
+//
+// RAW: the payload-input instantiations for plans with OFDMTX_F_RAW_PSDU (the packet's bytes are the
+// whole PSDU); separate for the same reason, regime dispatched per packet.
+template <bool UNIFORM, int REGIME, bool FROM_MSG, bool PNC = false, bool RAW = false>
 __global__ void __launch_bounds__(64 * TX_MAX_WAVES)
 k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ in, float2 *__restrict__ mapped,
      float2 *__restrict__ pilot_tap, float2 *__restrict__ cmap_tap, float2 *__restrict__ iq, uint32_t a_words,
@@ -1291,7 +1303,7 @@ k_tx(PlanParams P, DevTables T, const uint8_t *__restrict__ in, float2 *__restri
             }
             wave_sync();
         } else {
-            scramble_packet<8>(k, ri, T, in, A, U, s_crc, s_scr, lane, nullptr, nullptr);
+            scramble_packet<8, false, RAW>(k, ri, T, in, A, U, s_crc, s_scr, lane, nullptr, nullptr);
         }
 
         SEC("copy");
@@ -1448,7 +1460,8 @@ __host__ __device__ __forceinline__ PktGeom pkt_geometry(const RegimeInfo &ri, i
                                                           unsigned flags)
 {
     PktGeom g;
-    const int mpdu = 24 + payload_len;
+    // OFDMTX_F_RAW_PSDU: the caller's bytes are MPDU + FCS already, LENGTH is their count
+    const int mpdu = (flags & OFDMTX_F_RAW_PSDU) ? payload_len - 4 : 24 + payload_len;
     const int nbits = 16 + 32 + 6 + 8 * mpdu;
     g.n_sym = (nbits + ri.n_dbps - 1) / ri.n_dbps;                       // pu:85
     g.n_pad = g.n_sym * ri.n_dbps - nbits;                               // pu:94-97
@@ -1478,7 +1491,7 @@ __global__ void k_plan_geom(uint32_t n, const uint8_t *__restrict__ regimes, con
     const uint32_t len = lens[i];
     uint32_t err = 0;
     if (regime < 1 || regime > 8) err |= 1u;
-    if (len > (uint32_t)MAXLEN || 24u + len + 4u > (uint32_t)MAXLEN) err |= 2u;
+    if (len > (uint32_t)MAXLEN || (!(flags & OFDMTX_F_RAW_PSDU) && 24u + len + 4u > (uint32_t)MAXLEN)) err |= 2u;
     if (err) {
         atomicOr(&out->error, err);
         return;
@@ -1676,7 +1689,6 @@ int ofdmtx_packet_info(int regime, int payload_len, double symbol_time, unsigned
     if (regime < 1 || regime > 8) return OFDMTX_EREGIME;
     const RegimeInfo ri = regime_info(regime);
     const PktGeom g = pkt_geometry(ri, payload_len, symbol_time, flags);
-    const int mpdu = 24 + payload_len;
     out->n_cbps = ri.n_cbps;
     out->n_bpsc = ri.n_bpsc;
     out->n_dbps = ri.n_dbps;
@@ -1689,7 +1701,7 @@ int ofdmtx_packet_info(int regime, int payload_len, double symbol_time, unsigned
     out->msg_len = g.msg_len;
     out->n_rows = g.n_rows;
     // the length limit is ftw_make's (pu:119-121), get_info itself has none: *out is complete either way
-    return mpdu + 4 > MAXLEN ? OFDMTX_ELENGTH : OFDMTX_OK;
+    return g.length > MAXLEN ? OFDMTX_ELENGTH : OFDMTX_OK;
 }
 
 int ofdmtx_create(int device, ofdmtx_ctx **out)
@@ -1855,6 +1867,8 @@ static bool plan_modes_ok(int pilot_mode, unsigned flags)
     const unsigned roles = flags & (OFDMTX_F_PNC_A | OFDMTX_F_PNC_B);
     if (roles == (OFDMTX_F_PNC_A | OFDMTX_F_PNC_B)) return false;       // one role at a time
     if (roles && !(flags & OFDMTX_F_PREAMBLE)) return false;            // the role only shapes the preamble
+    // a raw PSDU with a PNC role or PNC pilots: no instantiation of the kernels covers the pair
+    if ((flags & OFDMTX_F_RAW_PSDU) && (roles || pilot_mode >= OFDMTX_PILOT_PNC_A)) return false;
     return true;
 }
 
@@ -2302,10 +2316,12 @@ int ofdmtx_encode_bits(ofdmtx_ctx *ctx, const ofdmtx_plan *pl, const uint8_t *d_
     const uint32_t a_words = pl->tx_u_words > pl->tx_m_words ? pl->tx_u_words : pl->tx_m_words;
     const uint32_t u_words = pl->tx_u_words;
     const size_t lds = (size_t)ENC_WAVES * (a_words + u_words) * sizeof(uint32_t);
-#define LAUNCH_ENC(U_, R_)                                                                           \
-    hipLaunchKernelGGL((k_encode_bits<U_, R_>), dim3(grid), dim3(64 * ENC_WAVES), lds, st, pp, tab,  \
+#define LAUNCH_ENC(U_, R_, ...)                                                                      \
+    hipLaunchKernelGGL((k_encode_bits<U_, R_, ##__VA_ARGS__>), dim3(grid), dim3(64 * ENC_WAVES), lds, st, pp, tab,  \
                        d_payloads, d_plcp, d_scrambled, d_coded, d_interleaved, a_words, u_words)
-    if (!pp.uniform) {
+    if (pp.flags & OFDMTX_F_RAW_PSDU) {
+        if (pp.uniform) LAUNCH_ENC(true, 0, true); else LAUNCH_ENC(false, 0, true);
+    } else if (!pp.uniform) {
         LAUNCH_ENC(false, 0);
     } else {
         switch (pp.regime) {
@@ -2368,6 +2384,11 @@ static int launch_tx(ofdmtx_ctx *ctx, const ofdmtx_plan *pl, const uint8_t *d_in
     const bool pnc = (pp.flags & (OFDMTX_F_PNC_A | OFDMTX_F_PNC_B)) || pp.pilot_mode >= OFDMTX_PILOT_PNC_A;
     if (pnc) {
         if (pp.uniform) LAUNCH_TX(true, 0, true); else LAUNCH_TX(false, 0, true);
+    } else if (!FROM_MSG && (pp.flags & OFDMTX_F_RAW_PSDU)) {
+        // (the message input does not care where the bits came from: the standard instantiations below)
+        if constexpr (!FROM_MSG) {
+            if (pp.uniform) LAUNCH_TX(true, 0, false, true); else LAUNCH_TX(false, 0, false, true);
+        }
     } else if (!pp.uniform) {
         LAUNCH_TX(false, 0);
     } else if (FROM_MSG) {

@@ -300,6 +300,28 @@ def encode_bits_from_mpdu(mpdu, regime, fcs=None):
     return {"plcp": pkt, "Length": length, "N_sym": n_sym, "scrambled": scr, "coded": cod, "interleaved": itl}
 
 
+def encode_bits_from_psdu(psdu, regime):
+    """The same chain for a whole PSDU (MPDU + FCS bytes in natural order, each sent least significant
+    bit first): what a plan with OFDMTX_F_RAW_PSDU transmits.  LENGTH = len(psdu); the PLCP string is
+    built as in ftw_make (ftw_packet_utils.py:128-205) with the bit-reversed PSDU in the place of
+    MPDU + FCS.  For four bytes or more this is encode_bits_from_mpdu(psdu[:-4], regime,
+    bit-reversed psdu[-4:])."""
+    psdu = bytes(psdu)
+    _, (rn, rd), n_cbps, n_bpsc, _ = REGIMES[regime]
+    n_dbps = int(n_cbps * (rn / float(rd)))
+    length = len(psdu)
+    if length > MAXLEN:
+        raise ValueError("MPDU-length must be in [0, %d]" % (MAXLEN,))
+    nbits = 16 + 8 * length + 6
+    n_sym = int(math.ceil(nbits / float(n_dbps)))
+    n_pad = n_sym * n_dbps - nbits
+    pkt = signal_field(regime, length) + b"\x00\x00" + _bitrev8(psdu) + b"\x00" * tail_and_pad_bytes(n_pad)
+    scr, _ = scrambler(pkt, length)
+    cod = conv_encoder(scr, length, regime, n_cbps, n_bpsc, n_sym, None)
+    itl = interleaver(cod, regime, n_cbps, n_bpsc)
+    return {"plcp": pkt, "Length": length, "N_sym": n_sym, "scrambled": scr, "coded": cod, "interleaved": itl}
+
+
 # --------------------------------------------------------------------------- a11: mapper
 
 def ofdm_mapper(msg, regime):

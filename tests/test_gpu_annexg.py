@@ -5,12 +5,17 @@ ofdmtx_interleave and the fused symbol-level kernel ofdmtx_modulate, all through
 
 The frame (36 Mbit/s = regime 6, 100-byte PSDU) carries a MAC header with frame control 0x0402 and the
 FCS printed in the standard, which is not the CRC-32 of the MPDU (matlab/encode.m:55-66,221-223: "force
-the WRONG CRC32 for the reference frame").  ofdmtx_tx / ofdmtx_encode_bits build the MAC header of
-examples/ftw_packet_utils.py:28-36 (frame control 0x0800) and a correct FCS themselves, so they cannot
-produce this frame; it enters at the PLCP byte string instead, which this test assembles by hand from
-the field definitions -- the kernels downstream (scrambler, encoder + 3/4 puncturing, 16-QAM
-interleaver, mapper, pilots, carrier map, inverse FFT, cyclic prefix, 1/8 scale, preamble) then see
-exactly the bits of the standard's example.  Tolerance: the table has 3 decimals (half an LSB in re
+the WRONG CRC32 for the reference frame").  With their ordinary plans ofdmtx_tx / ofdmtx_encode_bits build
+the MAC header of examples/ftw_packet_utils.py:28-36 (frame control 0x0800) and a correct FCS themselves,
+so the frame enters in two other ways:
+  * at the PLCP byte string, which the first test assembles by hand from the field definitions, into the
+    stage operators and ofdmtx_modulate;
+  * as a raw PSDU (plan flag OFDMTX_F_RAW_PSDU: the caller's bytes are MPDU + FCS) into the batched
+    kernels themselves -- ofdmtx_tx, the fused payload -> IQ kernel the headline is measured on, and
+    ofdmtx_encode_bits with all its taps.
+Either way the kernels downstream (scrambler, encoder + 3/4 puncturing, 16-QAM interleaver, mapper,
+pilots, carrier map, inverse FFT, cyclic prefix, 1/8 scale, preamble) see exactly the bits of the
+standard's example.  Tolerance: the table has 3 decimals (half an LSB in re
 and im: 7.1e-4) and is time-windowed at the symbol boundaries, which are left out
 (matlab/encode.m:421-446).
 """
@@ -91,3 +96,66 @@ def test_annex_g8_frame_through_the_kernels(txctx):
     boundary[[0, 160, 320] + list(range(400, 880, 80))] = True
     assert d[~boundary].max() < 1.5e-3, "HIP output differs from the Annex G.8 table by %.3g" % d[~boundary].max()
     assert d[boundary].min() > 0.02                              # the table's windowed samples really differ
+
+
+def annex_g_psdu():
+    """The 100 bytes a raw-PSDU plan takes: the MPDU and, behind it, the printed FCS packed like every
+    other PSDU byte (first transmitted bit = least significant)."""
+    fcs = bytes(int(FCS_BITS[i:i + 8][::-1], 2) for i in range(0, 32, 8))
+    return MPDU + fcs
+
+
+def check_against_table(iq880):
+    with open(os.path.join(ROOT, "tests", "golden", "ftw_tables.json")) as f:
+        table = np.array([complex(r, i) for r, i in json.load(f)["annex_g8_time"]])
+    d = np.abs(iq880.astype(np.complex128) / 8.0 - table[:880])  # matlab/encode.m:421-446: frame = 8 x table
+    boundary = np.zeros(880, bool)
+    boundary[[0, 160, 320] + list(range(400, 880, 80))] = True
+    assert d[~boundary].max() < 1.5e-3, "HIP output differs from the Annex G.8 table by %.3g" % d[~boundary].max()
+    assert d[boundary].min() > 0.02
+
+
+@pytest.mark.parametrize("ragged", [False, True], ids=["uniform", "ragged"])
+def test_annex_g8_frame_through_the_fused_kernel(txctx, ragged):
+    """The PSDU through ofdmtx_tx (k_tx, payload input): SIGNAL field, scrambler words, encoder,
+    puncturing and interleaving by multiplication, slot rows, transform -- one kernel, against the table.
+    The ragged plan puts two more packets around it, so the frame is not the batch's first."""
+    psdu = annex_g_psdu()
+    flags = _lib.F_PREAMBLE | _lib.F_RAW_PSDU
+    if ragged:
+        other = bytes(range(40))
+        plan = txctx.plan_ragged(np.array([3, 6, 8], np.uint8), np.array([len(other), len(psdu), len(other)], np.uint32),
+                                 pilot_mode=_lib.PILOT_PER_PACKET, pilot_start=0, flags=flags, amp=1.0)
+        data, which = other + psdu + other, 1
+    else:
+        plan = txctx.plan_uniform(1, 6, len(psdu), pilot_mode=_lib.PILOT_PER_PACKET, pilot_start=0, flags=flags, amp=1.0)
+        data, which = psdu, 0
+    lay = plan.layout()
+    assert lay["n_sym"][which] == 6 and lay["plcp_len"][which] == len(annex_g_plcp()[0])
+    pay = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(txctx.device)
+    iq = plan.tx(pay)
+    torch.cuda.synchronize()
+    a = int(lay["sample_off"][which])
+    check_against_table(iq.cpu().numpy()[a:a + 880])
+    # and bit for bit what the two-kernel path makes of the same plan
+    iq2 = plan.modulate(plan.encode_bits(pay))
+    assert torch.equal(iq.view(torch.float32), iq2.view(torch.float32))
+
+
+def test_annex_g8_bit_chain_taps_equal_the_oracle(txctx):
+    """ofdmtx_encode_bits (k_encode_bits) on the PSDU: every tap bit for bit what the oracle's chain gives
+    for the same MPDU and FCS (oracle.encode_bits_from_mpdu, itself pinned to the table by
+    tests/test_oracle.py), and the PLCP tap equal to the byte string assembled by hand above."""
+    from oracle import ftw_oracle as o
+    psdu = annex_g_psdu()
+    plan = txctx.plan_uniform(1, 6, len(psdu), pilot_mode=_lib.PILOT_PER_PACKET, flags=_lib.F_PREAMBLE | _lib.F_RAW_PSDU,
+                              amp=1.0)
+    taps = plan.encode_bits(torch.frombuffer(bytearray(psdu), dtype=torch.uint8).to(txctx.device), taps=True)
+    torch.cuda.synchronize()
+    ref = o.encode_bits_from_mpdu(MPDU, "6", o.bits_to_bytes(np.array([int(c) for c in FCS_BITS], np.uint8)))
+    lay = plan.layout()
+    plen, mlen = int(lay["plcp_len"][0]), int(lay["msg_len"][0])
+    assert ref["plcp"] == annex_g_plcp()[0]
+    for tap, key, n in (("plcp", "plcp", plen), ("scrambled", "scrambled", plen), ("coded", "coded", mlen),
+                        ("interleaved", "interleaved", mlen)):
+        assert taps[tap].cpu().numpy()[:n].tobytes() == ref[key], tap

@@ -21,8 +21,12 @@ def oracle_batch(c_oracle, payloads, lens, regimes, pilot_base, flags, amp, symb
     for i, (n, r) in enumerate(zip(lens, regimes)):
         pl = payloads[off:off + n].tobytes()
         off += n
-        enc = c_oracle.encode_bits(pl, int(r), symbol_time)
-        mod = c_oracle.modulate(enc["interleaved"], int(r), int(pilot_base[i]), amp, flags)
+        if flags & _lib.F_RAW_PSDU:                       # the packet's bytes are the whole PSDU
+            from oracle import ftw_oracle
+            enc = ftw_oracle.encode_bits_from_psdu(pl, str(int(r)))
+        else:
+            enc = c_oracle.encode_bits(pl, int(r), symbol_time)
+        mod = c_oracle.modulate(enc["interleaved"], int(r), int(pilot_base[i]), amp, flags & ~_lib.F_RAW_PSDU)
         enc.update(mod)
         out.append(enc)
     return out
@@ -113,6 +117,54 @@ def test_ragged_mixed_rates(txctx, c_oracle):
     flags = _lib.F_PREAMBLE | _lib.F_ZEROGAP
     plan = txctx.plan_ragged(regimes, lens, pilot_start=100, flags=flags, amp=0.3)
     check_plan(plan, payloads, lens.tolist(), regimes.tolist(), c_oracle, flags, 0.3)
+
+
+@pytest.mark.parametrize("regime", range(1, 9))
+def test_raw_psdu_uniform(txctx, c_oracle, regime):
+    """Plans with OFDMTX_F_RAW_PSDU: the caller's bytes are MPDU + FCS; every tap and the IQ against the
+    oracle's chain for the same PSDU, fused == two-kernel bitwise."""
+    flags = _lib.F_PREAMBLE | _lib.F_ZEROGAP | _lib.F_RAW_PSDU
+    for ln in (0, 1, 3, 4, 5, 100, 1528):
+        rng = np.random.default_rng(50 * regime + ln)
+        n = 4
+        psdus = rng.integers(0, 256, n * ln, dtype=np.uint8)
+        plan = txctx.plan_uniform(n, regime, ln, pilot_start=9, flags=flags, amp=0.3)
+        check_plan(plan, psdus, [ln] * n, [regime] * n, c_oracle, flags, 0.3)
+
+
+def test_raw_psdu_ragged_and_limits(txctx, c_oracle):
+    rng = np.random.default_rng(17)
+    n = 120
+    regimes = rng.integers(1, 9, n).astype(np.uint8)
+    lens = rng.integers(0, 2400, n).astype(np.uint32)
+    lens[:5] = [0, 1, 3168, 4, 2]
+    psdus = rng.integers(0, 256, int(lens.sum()), dtype=np.uint8)
+    flags = _lib.F_PREAMBLE | _lib.F_ZEROGAP | _lib.F_RAW_PSDU
+    plan = txctx.plan_ragged(regimes, lens, pilot_start=31, flags=flags, amp=0.3)
+    check_plan(plan, psdus, lens.tolist(), regimes.tolist(), c_oracle, flags, 0.3)
+    # the same plan built on the device
+    dev = txctx.device
+    plan_d = txctx.plan_ragged(torch.from_numpy(regimes).to(dev), torch.from_numpy(lens.astype(np.int32)).to(dev),
+                               pilot_start=31, flags=flags, amp=0.3)
+    check_plan(plan_d, psdus, lens.tolist(), regimes.tolist(), c_oracle, flags, 0.3)
+    # a PSDU is limited like MPDU + FCS (examples/ftw_packet_utils.py:119-121); PNC roles are refused
+    with pytest.raises(ValueError):
+        txctx.plan_uniform(1, 8, 3169, flags=flags)
+    with pytest.raises(_lib.OfdmTxError):
+        txctx.plan_uniform(1, 8, 100, flags=flags | _lib.F_PNC_A)
+    # an ordinary packet sent as a raw PSDU (own header, own CRC) gives the ordinary plan's samples, and
+    # the loop-back verifier returns the whole PSDU with a clean status
+    from oracle import ftw_oracle as o
+    payload = rng.integers(0, 256, 321, dtype=np.uint8).tobytes()
+    mpdu = o.get_info(payload, "8", 4.0)["packet"]
+    whole = mpdu + o._bitrev8(o.ftw_crc32(mpdu).to_bytes(4, "big"))
+    std = txctx.plan_uniform(1, 8, len(payload), amp=1.0)
+    raw = txctx.plan_uniform(1, 8, len(whole), amp=1.0, flags=flags)
+    iq_std = std.tx(torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(dev))
+    iq_raw = raw.tx(torch.frombuffer(bytearray(whole), dtype=torch.uint8).to(dev))
+    assert torch.equal(iq_std.view(torch.float32), iq_raw.view(torch.float32))
+    back, status = raw.loopback(iq_raw)
+    assert int(status.abs().max()) == 0 and back.cpu().numpy().tobytes() == whole
 
 
 def test_stream_pilot_counter_matches_flowgraph_order(txctx):

@@ -256,3 +256,25 @@ def test_pnc_pilot_block_user_0():
         p = o.ofdm_pilot(sym, 0, user)
         assert [p[1, i].real for i in (5, 19, 33, 47)] == list(want)
         assert not np.delete(p, (5, 19, 33, 47), axis=1).any()
+
+
+def test_psdu_entry_equals_the_mpdu_entry():
+    """encode_bits_from_psdu (what raw-PSDU plans are checked against) is encode_bits_from_mpdu with the
+    FCS taken from the PSDU's last four bytes, for the Annex G frame and for random ones; and for an
+    ordinary packet with its own header and CRC it is encode_bits."""
+    fcs_tx = o.bits_to_bytes(np.array(ANNEX_G_FCS_BITS, np.uint8))
+    psdu = ANNEX_G_MPDU + o._bitrev8(fcs_tx)
+    assert o.encode_bits_from_psdu(psdu, "6") == o.encode_bits_from_mpdu(ANNEX_G_MPDU, "6", fcs_tx)
+    rng = np.random.default_rng(5)
+    for regime in "12345678":
+        n = int(rng.integers(4, 400))
+        p = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        assert o.encode_bits_from_psdu(p, regime) == o.encode_bits_from_mpdu(p[:-4], regime, o._bitrev8(p[-4:]))
+        payload = rng.integers(0, 256, 77, dtype=np.uint8).tobytes()
+        full = o.encode_bits(payload, regime)
+        mpdu = o.get_info(payload, regime, 4.0)["packet"]
+        whole = mpdu + o._bitrev8(o.ftw_crc32(mpdu).to_bytes(4, "big"))
+        raw = o.encode_bits_from_psdu(whole, regime)
+        assert all(raw[k] == full[k] for k in ("plcp", "scrambled", "coded", "interleaved"))
+    short = o.encode_bits_from_psdu(b"\x5a", "1")        # fewer than four bytes: no FCS to speak of
+    assert short["Length"] == 1 and short["N_sym"] == 2 and short["plcp"][3:6] == b"\x00\x00\x5a"
