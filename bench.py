@@ -153,16 +153,19 @@ def alloc_output(ctx, n_samples, mode, fill, candidates=5, compare=True):
     if mode == "spread":
         t_alloc = time.perf_counter()
         try:
-            raw, spread = ctx.alloc_spread(n_samples * 8)
+            raw, spread = ctx.alloc_spread(n_samples * 8, parts=3)
         except _lib.OfdmTxError:                          # (e.g. another process took the memory meanwhile)
             raw, spread = torch.empty(n_samples * 8, dtype=torch.uint8, device=dev), False
         t_alloc = time.perf_counter() - t_alloc
         iq = raw.view(torch.complex64)
         if spread:
-            rec = {"mode": "spread", "note": "64 MiB pieces alternating between the three parts of the device memory "
-                                             "(ofdmtx_stream_alloc); one launch timed into it and (unless --placement-compare "
-                                             "0) into an ordinary first allocation, which is freed before the timed region",
-                   "alloc_s": round(t_alloc, 2), "spread_ms": round(once(iq), 3)}
+            rec = {"mode": "spread", "note": "64 MiB pieces alternating between `parts` of the device memory's three parts, "
+                                             "found by timing writes into the memory taken (ofdmtx_stream_alloc; peak_held_GB "
+                                             "= what it held while it looked); one "
+                                             "launch timed into it and (unless --placement-compare 0) into an ordinary first "
+                                             "allocation, which is freed before the timed region",
+                   "alloc_s": round(t_alloc, 3), "peak_held_GB": round(ctx.last_alloc["peak_held_bytes"] / 1e9, 1),
+                   "handles": ctx.last_alloc["handles"], "parts": ctx.last_alloc["parts"], "spread_ms": round(once(iq), 3)}
             rec["kept"] = "spread"
             if compare:
                 plain = torch.empty(n_samples, dtype=torch.complex64, device=dev)

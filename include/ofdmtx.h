@@ -402,16 +402,31 @@ int ofdmtx_raw_tx(ofdmtx_ctx *ctx, const ofdmtx_raw_plan *plan, int qambits, int
 
 /* ---- placement of a large, long-lived output buffer ----------------------------------------------
  * No counterpart in the reference (its sinks own their buffers).  On MI355X streaming stores into a
- * buffer that lies in one of the memory's three 96 GiB parts run at 5.6-5.7 TB/s, into a buffer
- * whose pieces alternate between the parts at 7.1 TB/s.  ofdmtx_stream_alloc returns `bytes` of
- * device memory made of 64 MiB pieces taken in turn from three far-apart places of the device
- * (HIP virtual-memory API; for the duration of the call it takes nearly all free memory of the
- * device as such pieces and gives the unused ones back), usable like any device pointer for d_iq.
- * *spread (may be NULL) tells whether that worked; with less than three quarters of the device
- * free, or on any failure on the way, the buffer is an ordinary hipMalloc allocation and *spread is
- * 0.  ofdmtx_stream_free releases either kind (after a device synchronisation); the buffer may
- * outlive the context it was made with (any non-NULL ctx is accepted then). */
+ * buffer that lies in one of the memory's three 96 GiB parts run at 5.6-5.9 TB/s, into a buffer
+ * whose pieces alternate between parts at 6.8-7.1 TB/s.  ofdmtx_stream_alloc returns `bytes` of
+ * device memory made of 64 MiB pieces that alternate between two or three parts (HIP virtual-memory
+ * API), usable like any device pointer for d_iq.  Which part a piece of physical memory lies in is
+ * not visible to a process, so the call finds out by measurement: it takes memory 16 GiB at a time,
+ * times every 2 GiB of it being written together with the first 2 GiB, stops when it has pieces of
+ * two different parts in equal shares, and gives the rest back.  It therefore holds more than the
+ * buffer for a moment (typically 100-140 GiB on an empty device, where the second part begins 96 GiB
+ * into the allocation order; up to all free memory but 2 GiB), synchronises the device and runs
+ * short kernels on the default stream: a call for set-up time, serialised inside the library.
+ * ofdmtx_stream_alloc_parts with want_parts = 3 goes on until all three parts are there (about
+ * 210 GiB into an empty device; it settles for two when the memory ends first): with the transmit
+ * kernel's payload reads beside the stores three parts are 2-4 % faster than two.  *spread (may be NULL) tells whether the layout was
+ * built; when only one part shows up within the free memory, or on any failure on the way, the
+ * buffer is an ordinary hipMalloc allocation and *spread is 0.  ofdmtx_stream_info reports what a
+ * buffer cost to build: its mapped size, the most physical memory held at one time while it was
+ * built, the number of handles created and the number of parts its pieces alternate between (0 for
+ * an ordinary allocation); each output may be NULL; OFDMTX_EINVAL for a pointer that is not such a
+ * buffer.  With OFDMTX_ALLOC_TRACE set in the environment the measurement is printed to stderr.
+ * ofdmtx_stream_free releases either kind (after a device synchronisation); the buffer may outlive
+ * the context it was made with (any non-NULL ctx is accepted then). */
 int ofdmtx_stream_alloc(ofdmtx_ctx *ctx, uint64_t bytes, void **out, int *spread);
+int ofdmtx_stream_alloc_parts(ofdmtx_ctx *ctx, uint64_t bytes, int want_parts, void **out, int *spread);
+int ofdmtx_stream_info(const void *ptr, uint64_t *bytes, uint64_t *peak_held_bytes, uint32_t *handles,
+                       uint32_t *parts);
 int ofdmtx_stream_free(ofdmtx_ctx *ctx, void *ptr);
 
 /* ---- optional exchange: the ranks' IQ shards into one buffer on a root GPU -----------------------

@@ -85,6 +85,9 @@ PROTOTYPES = {
     "ofdmtx_raw_modulate": (C.c_int, [_VP] * 6),
     "ofdmtx_raw_taps": (C.c_int, [_VP] * 8),
     "ofdmtx_stream_alloc": (C.c_int, [_VP, C.c_uint64, C.POINTER(_VP), C.POINTER(C.c_int)]),
+    "ofdmtx_stream_alloc_parts": (C.c_int, [_VP, C.c_uint64, C.c_int, C.POINTER(_VP), C.POINTER(C.c_int)]),
+    "ofdmtx_stream_info": (C.c_int, [_VP, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32),
+                                     C.POINTER(C.c_uint32)]),
     "ofdmtx_stream_free": (C.c_int, [_VP, _VP]),
     "ofdmtx_comm_unique_id": (C.c_int, [_VP]),
     "ofdmtx_comm_create": (C.c_int, [_VP, C.c_int, C.c_int, _VP, C.POINTER(_VP)]),

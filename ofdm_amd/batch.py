@@ -5,6 +5,7 @@ kernels behind the C ABI (ofdm_amd/_lib.py).  Names follow the reference's domai
 PLCP bytes, mapper messages, OFDM symbols, IQ samples.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -36,21 +37,112 @@ class _StreamMemory(object):
     """Device memory from ofdmtx_stream_alloc, presented to torch through the CUDA array interface;
     released when the last tensor that views it is gone."""
 
-    def __init__(self, ctx, n_bytes):
+    def __init__(self, ctx, n_bytes, parts=2):
         self._lib, self._ctx_h, self._ctx = ctx._lib, ctx._h, ctx          # (keeps the context alive)
         ptr, spread = C.c_void_p(), C.c_int()
-        _lib.check(self._lib.ofdmtx_stream_alloc(ctx._h, int(n_bytes), C.byref(ptr), C.byref(spread)))
+        _lib.check(self._lib.ofdmtx_stream_alloc_parts(ctx._h, int(n_bytes), int(parts), C.byref(ptr), C.byref(spread)))
         self.ptr, self.n_bytes, self.spread = ptr.value, int(n_bytes), bool(spread.value)
+        size, peak, handles, parts = C.c_uint64(), C.c_uint64(), C.c_uint32(), C.c_uint32()
+        _lib.check(self._lib.ofdmtx_stream_info(ptr, C.byref(size), C.byref(peak), C.byref(handles), C.byref(parts)))
+        self.peak_held_bytes, self.handles, self.parts = int(peak.value), int(handles.value), int(parts.value)
         self.__cuda_array_interface__ = {"shape": (self.n_bytes,), "typestr": "|u1", "data": (self.ptr, False),
                                          "version": 2, "strides": None}
 
     def __del__(self):
-        try:
-            if getattr(self, "ptr", None):
-                self._lib.ofdmtx_stream_free(self._ctx_h, C.c_void_p(self.ptr))
-                self.ptr = None
-        except Exception:
-            pass
+        if getattr(self, "ptr", None):
+            ptr, self.ptr = self.ptr, None
+            rc = self._lib.ofdmtx_stream_free(self._ctx_h, C.c_void_p(ptr))
+            if rc:                               # (a destructor cannot raise: say so instead of losing it)
+                import sys
+                sys.stderr.write("ofdm_amd: ofdmtx_stream_free failed (%d, HIP error %d): %d bytes of device memory stay "
+                                 "mapped\n" % (rc, self._lib.ofdmtx_last_hip_error(), self.n_bytes))
+
+
+class OutputRing(object):
+    """A long-lived output buffer of `slots` equal parts in ONE allocation whose 64 MiB pieces alternate
+    between the three parts of the device memory (TxContext.alloc_spread): what a streaming
+    transmitter writes its batches into, batch k into slot k % slots, instead of a fresh allocation
+    per batch.  With two slots the kernels of batch k + 1 fill one slot while the consumer of batch k
+    (a sink's copy to the host) still reads the other.  The caller orders reuse: take(n) hands out the
+    next slot without waiting for anything; a slot comes round again after `slots` calls.
+
+    slot_bytes is rounded up to 192 MiB (three pieces, one of each part)."""
+
+    GRAIN = 3 * (64 << 20)
+
+    def __init__(self, ctx, slot_bytes, slots=2, spread=True):
+        self.ctx, self.slots = ctx, int(slots)
+        self.slot_bytes = -(-int(slot_bytes) // self.GRAIN) * self.GRAIN
+        if spread:
+            mem = _StreamMemory(ctx, self.slot_bytes * self.slots)
+            self.spread, self.peak_held_bytes, self.handles, self.parts = mem.spread, mem.peak_held_bytes, mem.handles, mem.parts
+            self._raw = torch.as_tensor(mem, device=ctx.device)
+        else:                                    # one ordinary allocation, placed as it comes
+            self._raw = torch.empty(self.slot_bytes * self.slots, dtype=torch.uint8, device=ctx.device)
+            self.spread, self.peak_held_bytes, self.handles, self.parts = False, self._raw.numel(), 0, 0
+        self._next = 0
+
+    def take(self, n_samples):
+        """The next slot's first n_samples complex64 samples."""
+        if n_samples * 8 > self.slot_bytes:
+            raise ValueError("a slot holds %d samples, asked for %d" % (self.slot_bytes // 8, n_samples))
+        k, self._next = self._next, (self._next + 1) % self.slots
+        return self._raw[k * self.slot_bytes:k * self.slot_bytes + n_samples * 8].view(torch.complex64)
+
+
+class StreamOutput(object):
+    """The output side of a streaming transmitter (ofdm_mod, rawofdm's TX): where each batch's IQ is
+    written and when the sinks get it.
+
+    Large batches go into the slots of an OutputRing (made at the first large batch, sized by it, two
+    slots per buffer a batch needs) and reach their sinks one batch late: batch k is handed over
+    after the kernels of batch k + 1 have been enqueued, so the device works on k + 1 while the host
+    copies k out and writes it (the sinks' write() is synchronous: when it returns the slot may be
+    reused, which happens two batches later).  drain() hands over what is still waiting (end of
+    stream).  Small batches (below RING_MIN_BYTES) get an ordinary allocation each and are handed over
+    at once, in order."""
+
+    RING_MIN_BYTES = 256 << 20
+
+    def __init__(self, ctx, spread=None):
+        """spread: the ring's memory alternates between parts of the device memory (placing it costs
+        0.2-3 s once, at the first large batch, and holds tens of GiB for that moment; stores into it
+        run up to 25 % faster).  None: yes, unless OFDM_AMD_SPREAD_OUTPUT=0 is set in the environment.
+        False: one ordinary allocation."""
+        self.ctx = ctx
+        self.spread = (os.environ.get("OFDM_AMD_SPREAD_OUTPUT", "1") != "0") if spread is None else bool(spread)
+        self.ring = None
+        self._per_batch = 1
+        self._waiting = []           # (sink, tensor) of the batch not yet handed over
+
+    def buffer(self, n_samples, per_batch=1):
+        """Where a batch's IQ goes: a ring slot (complex64 tensor of n_samples), or None for a small
+        batch (the kernel wrapper then allocates).  per_batch: buffers every batch needs (one per
+        distinct amplitude among the connections)."""
+        need = int(n_samples) * 8
+        if need < self.RING_MIN_BYTES:
+            return None
+        if self.ring is None or self.ring.slot_bytes < need or self._per_batch != per_batch:
+            self.drain()
+            torch.cuda.synchronize(self.ctx.device)          # nothing may still write the old ring
+            self.ring = None
+            self.ring = OutputRing(self.ctx, need, 2 * per_batch, self.spread)
+            self._per_batch = per_batch
+        return self.ring.take(n_samples)
+
+    def hand_over(self, writes, ringed):
+        """writes: [(sink, tensor)] of the batch just enqueued; ringed: its tensors are ring slots."""
+        if ringed:
+            before, self._waiting = self._waiting, list(writes)
+        else:
+            before, self._waiting = self._waiting + list(writes), []
+        for sink, t in before:
+            sink.write(t)
+
+    def drain(self):
+        before, self._waiting = self._waiting, []
+        for sink, t in before:
+            sink.write(t)
 
 
 class TxContext:
@@ -77,14 +169,20 @@ class TxContext:
         except Exception:
             pass
 
-    def alloc_spread(self, n_bytes):
+    def alloc_spread(self, n_bytes, parts=2):
         """n_bytes of device memory (uint8 tensor) whose 64 MiB pieces alternate between the parts of
         the device memory (ofdmtx_stream_alloc): streaming stores into it run at up to 7.1 instead of
-        5.7 TB/s on MI355X.  Meant for long-lived output buffers: the call takes most of the device's
-        free memory for a moment (seconds).  Returns (tensor, spread) -- spread False: the device
+        5.7 TB/s on MI355X.  Meant for long-lived output buffers made at set-up time: for a moment (a
+        fraction of a second on a quiet device) the call holds most of the device's free memory.  Returns (tensor, spread) -- spread False: the device
         could not provide the layout and the buffer is an ordinary allocation."""
-        mem = _StreamMemory(self, int(n_bytes))
+        mem = _StreamMemory(self, int(n_bytes), parts)
+        self.last_alloc = {"spread": mem.spread, "peak_held_bytes": mem.peak_held_bytes, "handles": mem.handles,
+                           "parts": mem.parts}
         return torch.as_tensor(mem, device=self.device), mem.spread
+
+    def output_ring(self, slot_bytes, slots=2, spread=True):
+        """An OutputRing of `slots` slots of at least slot_bytes each on this context's device."""
+        return OutputRing(self, slot_bytes, slots, spread)
 
     def set_constellation(self, n_bpsc, points):
         """`constellation` argument of ftw.ofdm_mapper for DATA symbols with n_bpsc bits/carrier."""
@@ -242,9 +340,9 @@ class TxPlan:
     def alloc_iq(self):
         return torch.empty(self.n_samples, dtype=torch.complex64, device=self.ctx.device)
 
-    def alloc_iq_spread(self):
+    def alloc_iq_spread(self, parts=2):
         """The plan's output buffer from TxContext.alloc_spread: (complex64 tensor, spread)."""
-        t, spread = self.ctx.alloc_spread(self.n_samples * 8)
+        t, spread = self.ctx.alloc_spread(self.n_samples * 8, parts)
         return t.view(torch.complex64), spread
 
     def alloc_iq_probed(self, fill, max_candidates=5, reserve_bytes=8 << 30, launches=2):

@@ -18,7 +18,7 @@ from . import _lib
 from . import ftw
 from . import gr
 from . import ftw_packet_utils as ofdm_packet_utils
-from .batch import TxContext
+from .batch import StreamOutput, TxContext
 
 # symbols modulated so far in this process (ftw/ftw_ofdm_pilot_cc.cc:82: a file-scope counter)
 _pilot_offset = [0]
@@ -29,9 +29,11 @@ class ofdm_mod(gr.hier_block2):
 
     options: regime (str "1".."8"), interp, swapIQ, log, role (None, 'A' or 'B': the PNC pilot,
     preamble and zero-gap blocks of :101-106,133-138,147-149).  batch_packets bounds
-    how many queued packets are modulated per kernel launch."""
+    how many queued packets are modulated per kernel launch.  spread_output: see batch.StreamOutput
+    (where the IQ of large batches is written)."""
 
-    def __init__(self, options, payload='', msgq_limit=2, pad_for_usrp=False, batch_packets=65536, device=None):
+    def __init__(self, options, payload='', msgq_limit=2, pad_for_usrp=False, batch_packets=65536, device=None,
+                 spread_output=None):
         gr.hier_block2.__init__(self, "ofdm_mod")
         self._fft_length = 64
         self._total_sub_carriers = 53
@@ -90,6 +92,7 @@ class ofdm_mod(gr.hier_block2):
         self._log_files = {}
         self._plans = collections.OrderedDict()    # uniform plans of recent batches
         self._live = []              # plans and buffers of the last flush: kept until the next one has been enqueued
+        self._output = StreamOutput(self._ctx, spread_output)     # ring of output slots + hand-over to the sinks
         self._pinned = None          # page-locked staging buffer for the payload bytes
         self._pinned_free = None     # event: the copy out of it has finished
         self._dev_payloads = None
@@ -103,6 +106,7 @@ class ofdm_mod(gr.hier_block2):
 
     def _finish(self):
         self._flush()
+        self._output.drain()
         for f in self._log_files.values():
             f.close()
         self._log_files = {}
@@ -113,6 +117,7 @@ class ofdm_mod(gr.hier_block2):
         if eof:
             self._eof = True
             self._flush()
+            self._output.drain()
             return
         payload = ofdm_packet_utils._as_bytes(payload)
         if 24 + len(payload) + 4 > ofdm_packet_utils.MAXLEN:
@@ -195,24 +200,32 @@ class ofdm_mod(gr.hier_block2):
             live.append(p1)
         # one kernel launch per distinct amplitude among the connections (the amplitude is folded
         # into the transform's twiddles, examples/ftw_ofdm_tx_uhd.py:82-86)
-        done = {}
-        n_symbols = None
-        for gain, sink in (self._outs or [(None, None)]):
+        # Large batches are written into the slots of a ring whose memory alternates between the parts of
+        # the device (StreamOutput) and reach the sinks one batch late, under the next batch's kernels.
+        outs = self._outs or [(None, None)]
+        amps = {float(g.k()) if g is not None else 1.0 for g, _ in outs}
+        done, writes = {}, []
+        n_symbols, ringed = None, False
+        for gain, sink in outs:
             amp = float(gain.k()) if gain is not None else 1.0
             if amp not in done:
                 if amp == 1.0 and unit is not None and not self._swap:
                     done[amp] = unit
                 else:
                     plan = self._plan(lens, amp, flags, pilot_mode, start)
-                    done[amp] = plan.tx(payloads)
+                    slot = self._output.buffer(plan.n_samples, len(amps))
+                    ringed = ringed or slot is not None
+                    done[amp] = plan.tx(payloads, out=slot)[:plan.n_samples]
                     n_symbols = plan.n_symbols
                     live.append(plan)
             if sink is not None:
-                sink.write(done[amp])
+                writes.append((sink, done[amp]))
         if n_symbols is None:
             n_symbols = live[-1].n_symbols
         _pilot_offset[0] += n_symbols
+        # (a ring slot is written again two batches later: last_iq is good until then)
         self.last_iq = next(iter(done.values()))
+        self._output.hand_over(writes, ringed)
         self._live = live            # the previous flush's plans and buffers may go now: this one is enqueued behind them
 
 

@@ -17,13 +17,14 @@ import torch
 
 from . import gr
 from . import raw
+from .batch import StreamOutput
 
 
 class TX(gr.hier_block2):
     """rawofdm/examples/ofdm_rxtx.py:63-98.  Input: data_tones complex values per symbol (connect a
     vector_source_c, e.g. make_data's); output: baseband samples to the connected sinks."""
 
-    def __init__(self, options, ctx=None, device=0, batch_frames=65536):
+    def __init__(self, options, ctx=None, device=0, batch_frames=65536, spread_output=None):
         gr.hier_block2.__init__(self, "TX")
         self.tx = raw.ofdm_mod(options, ctx=ctx, device=device)
         self.params = self.tx.params
@@ -33,6 +34,8 @@ class TX(gr.hier_block2):
         self._frames = 0
         self._batch_frames = int(batch_frames)
         self.last_iq = None
+        self._output = None          # ring of output slots + hand-over to the sinks (made at the first flush)
+        self._spread_output = spread_output      # see batch.StreamOutput
 
     # ---- wiring (ofdm_amd.gr.top_block.connect)
     def _set_source(self, src):
@@ -48,6 +51,8 @@ class TX(gr.hier_block2):
 
     def _finish(self):
         self._flush()
+        if self._output is not None:
+            self._output.drain()
 
     # ---- the reference's interface
     def send_packet(self, num=1):
@@ -59,6 +64,8 @@ class TX(gr.hier_block2):
     def send_eof(self):
         """ofdm_rxtx.py:89-92."""
         self._flush()
+        if self._output is not None:
+            self._output.drain()
 
     def _flush(self):
         n, self._frames = self._frames, 0
@@ -67,17 +74,38 @@ class TX(gr.hier_block2):
         if self._source is None:
             raise RuntimeError("TX: no data source connected")
         data = self._source.take(n * self.size, self.tx.ctx.device)
-        iq = self.tx.modulate_frames(data, self.size)
-        self.last_iq = iq
+        # Large batches go into the slots of a ring whose memory alternates between the parts of the
+        # device and reach the sinks one batch late, under the next batch's kernels (StreamOutput); there
+        # a gain block scales the slot in place, once (the connections of one TX share one gain in the
+        # reference's scripts, ofdm_tx.py:48-52; differing gains, and small batches, get copies).
+        if self._output is None:
+            self._output = StreamOutput(self.tx.ctx, self._spread_output)
+        taken = []
+
+        def where(n_samples):
+            taken.append(self._output.buffer(n_samples))
+            return taken[-1]
+
+        iq = self.tx.modulate_frames(data, self.size, out=where)
+        ringed = bool(taken) and taken[0] is not None
+        self.last_iq = iq            # (a ring slot: scaled in place below, written again two batches later)
+        ctx = self.tx.ctx
+        gains = {complex(g.k()) for g, _ in self._outs if g is not None}
+        in_place = ringed and len(gains) == 1 and all(g is not None for g, _ in self._outs)
+        writes = []
+        scaled = {}
         for gain, sink in self._outs:
             out = iq
             if gain is not None:
                 k = complex(gain.k())
-                out = torch.empty_like(iq)
-                ctx = self.tx.ctx
-                raw._lib.check(ctx._lib.ofdmtx_scale_cc(ctx._h, raw._ptr(iq), iq.numel(), k.real, k.imag, raw._ptr(out),
-                                                        raw._stream(ctx.device)))
-            sink.write(out)
+                if k not in scaled:
+                    out = iq if in_place else torch.empty_like(iq)
+                    raw._lib.check(ctx._lib.ofdmtx_scale_cc(ctx._h, raw._ptr(iq), iq.numel(), k.real, k.imag, raw._ptr(out),
+                                                            raw._stream(ctx.device)))
+                    scaled[k] = out
+                out = scaled[k]
+            writes.append((sink, out))
+        self._output.hand_over(writes, ringed)
 
     @staticmethod
     def add_options(normal, expert):

@@ -239,14 +239,17 @@ class ofdm_mod(object):
         self.fused = False          # whether the last modulate_bytes ran as one kernel
         self._frame_plans = {}      # (n_frames, frame_size) -> RawPlan; a plan uploads tables and transforms the preambles
 
-    def _finish(self, plan, data):
+    def _finish(self, plan, data, out=None):
+        """out: None, or a function n_samples -> complex64 buffer (or None) for the plan's IQ."""
+        if out is not None:
+            out = out(plan.n_samples)
         if self._log:                                               # raw_ofdm_mod.py:54-66
-            iq, mapped = plan.modulate(data, want_mapped=True)
+            iq, mapped = plan.modulate(data, want_mapped=True, out=out)
             mapped.cpu().numpy().tofile("tx-map.dat")
             for name, t in plan.taps(mapped, iq).items():
                 t.cpu().numpy().tofile("tx-%s.dat" % name)
             return iq
-        return plan.modulate(data)
+        return plan.modulate(data, out=out)
 
     def _plan_frames(self, n_frames, frame_size):
         """Plans for back-to-back frames are kept: a stream of equal batches builds its plan once."""
@@ -271,13 +274,14 @@ class ofdm_mod(object):
         plan = plan_flags(self.ctx, p.fft_length, p.cp_length, p.padded_carriers, p.padded_preambles, flags)
         return self._finish(plan, data)
 
-    def modulate_frames(self, data, frame_size):
+    def modulate_frames(self, data, frame_size, out=None):
+        """out: see _finish (where the IQ goes; default: a fresh allocation)."""
         p = self.params
         data = self._as_device(data)
         n_sym = data.numel() // p.data_tones
         if n_sym % frame_size:
             raise ValueError("data does not hold whole frames")
-        return self._finish(self._plan_frames(n_sym // frame_size, frame_size), data)
+        return self._finish(self._plan_frames(n_sym // frame_size, frame_size), data, out)
 
     def modulate_bytes(self, bitrate, data, nsymbols, out=None):
         """qam_tx(bitrate, data_tones, nsymbols) feeding modulate_frames (rawofdm/examples/

@@ -194,9 +194,14 @@ def test_c1_one_packet_6mbps_to_file(txctx, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ring", [False, True], ids=["allocations", "ring"])
 @pytest.mark.parametrize("regime,swap", [("8", False), ("6", True), ("3", False)])
-def test_stream_of_packets_keeps_pilot_counter(txctx, tmp_path, regime, swap):
-    from ofdm_amd import ftw_ofdm, ftw_ofdm_tx, gr
+def test_stream_of_packets_keeps_pilot_counter(txctx, tmp_path, monkeypatch, regime, swap, ring):
+    """ring: every batch counts as large -- it is written into a slot of the output ring (a buffer whose
+    pieces alternate between the parts of the device memory) and handed to the sinks one batch late."""
+    from ofdm_amd import batch, ftw_ofdm, ftw_ofdm_tx, gr
+    if ring:
+        monkeypatch.setattr(batch.StreamOutput, "RING_MIN_BYTES", 1)
     rng = np.random.default_rng(3)
     lens = [1500, 1500, 40, 733, 0, 1500]
     payloads = [rng.integers(0, 256, n, dtype=np.uint8).tobytes() for n in lens]
@@ -205,12 +210,17 @@ def test_stream_of_packets_keeps_pilot_counter(txctx, tmp_path, regime, swap):
     tb = ftw_ofdm_tx.my_top_block(opt, payloads[0])
     sink = gr.vector_sink_c()
     tb.connect(tb.txpath, tb.amp, sink)
-    tb.txpath.ofdm_tx._batch_packets = 4               # two batches: 4 + 2 packets
+    tb.txpath.ofdm_tx._batch_packets = 4 if not ring else 2     # two batches: 4 + 2 packets (ring: three of 2)
     tb.start()
-    for p in payloads:
+    for i, p in enumerate(payloads):
         tb.txpath.send_pkt(p)
+        if ring and i == 3:                            # two batches enqueued, the first handed over
+            assert tb.sink.items_seen == sum(ftw_ofdm.ofdm_packet_utils.get_info(q, regime, 4.0)["N_sym"] + 18
+                                             for q in payloads[:2]) * 80
     tb.txpath.send_pkt(eof=True)
     tb.wait()
+    out = tb.txpath.ofdm_tx._output
+    assert (out.ring is not None) == ring and (not ring or (out.ring.slots == 2 and out.ring.slot_bytes == 192 << 20))
     off = off0
     ref = []
     for p in payloads:

@@ -322,6 +322,10 @@ def test_spread_output_buffer(txctx):
     assert iq.dtype == torch.complex64 and iq.numel() == plan.n_samples and iq.device == txctx.device
     if free0 > 0.8 * total:
         assert spread, "a nearly empty device must provide the layout"
+        # 144 MB = 3 pieces of 64 MiB; memory was taken 16 GiB (256 handles) at a time until a second part showed up
+        cost = txctx.last_alloc
+        assert cost["spread"] and cost["parts"] in (2, 3) and cost["handles"] % 256 == 0
+        assert (16 << 30) <= cost["peak_held_bytes"] == cost["handles"] * (64 << 20) < free0
     iq.zero_()
     plan.tx(pay, out=iq)
     torch.cuda.synchronize()
@@ -333,7 +337,7 @@ def test_spread_output_buffer(txctx):
     del part
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info(txctx.device)
-    assert free0 - free1 < (256 << 20), "the buffer's memory did not return to the device"
+    assert free0 - free1 < (32 << 20), "the buffer's memory (3 x 64 MiB) did not return to the device"
     lib = txctx._lib
     assert lib.ofdmtx_stream_free(txctx._h, C.c_void_p(want.data_ptr())) == _lib.EINVAL
     ptr = C.c_void_p()
@@ -341,16 +345,18 @@ def test_spread_output_buffer(txctx):
 
 
 def test_spread_allocation_falls_back_when_the_device_is_occupied(txctx):
-    """With less than three quarters of the device free the pieces cannot be taken from far-apart places:
-    the call still returns usable memory (an ordinary allocation) and says so; two buffers can be live at once."""
+    """With most of the device taken no second part shows up within the free memory: the call still
+    returns usable memory (an ordinary allocation) and says so; two buffers can be live at once."""
     torch.cuda.empty_cache()
     free0, total = torch.cuda.mem_get_info(txctx.device)
     if free0 < 0.8 * total:
         pytest.skip("the device is not empty enough to stage this")
     first, spread1 = txctx.alloc_spread(1 << 30)
-    hog = torch.empty(int(0.5 * total), dtype=torch.uint8, device=txctx.device)       # half of the device
+    assert spread1 and txctx.last_alloc["parts"] >= 2
+    free_now, _ = torch.cuda.mem_get_info(txctx.device)
+    hog = torch.empty(free_now - (6 << 30), dtype=torch.uint8, device=txctx.device)    # all but 6 GiB: too little to look for parts in
     second, spread2 = txctx.alloc_spread(1 << 30)
-    assert spread1 and not spread2
+    assert not spread2 and txctx.last_alloc["parts"] == 0
     first.fill_(7)
     second.fill_(9)
     torch.cuda.synchronize()
@@ -359,4 +365,23 @@ def test_spread_allocation_falls_back_when_the_device_is_occupied(txctx):
     torch.cuda.empty_cache()
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info(txctx.device)
-    assert free0 - free1 < (256 << 20)
+    assert free0 - free1 < (64 << 20)                  # (two buffers of 1 GiB were live)
+
+
+def test_spread_allocation_with_three_parts(txctx):
+    """ofdmtx_stream_alloc_parts(want_parts = 3) on an empty device: pieces of all three parts, found further
+    into the memory than two; the buffer works like any other."""
+    torch.cuda.empty_cache()
+    free0, total = torch.cuda.mem_get_info(txctx.device)
+    if free0 < 0.9 * total:
+        pytest.skip("the device is not empty enough to reach the third part")
+    buf, spread = txctx.alloc_spread(3 << 30, parts=3)
+    cost = txctx.last_alloc
+    # (a device with a history may show all three parts early on; one that has only just been handed over
+    #  shows them in turn, the third about 192 GiB in; two parts only after the whole free memory was looked at)
+    assert spread and (cost["parts"] == 3 or (cost["parts"] == 2 and cost["peak_held_bytes"] > 0.9 * free0 - (4 << 30)))
+    buf.fill_(5)
+    torch.cuda.synchronize()
+    assert int(buf[0]) == 5 and int(buf[-1]) == 5 and buf.numel() == 3 << 30
+    ptr = C.c_void_p()
+    assert txctx._lib.ofdmtx_stream_alloc_parts(txctx._h, 1 << 20, 4, C.byref(ptr), None) == _lib.EINVAL

@@ -587,11 +587,16 @@ def test_make_data_is_the_reference_generator():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ring", [False, True], ids=["allocations", "ring"])
 @pytest.mark.parametrize("kw,burst,numpkts", [(dict(), 1, 5), (dict(fft_length=256, occupied_tones=208, cp_length=64, size=7), 3, 10)])
-def test_tx_driven_like_sender_thread(txctx, tmp_path, kw, burst, numpkts):
+def test_tx_driven_like_sender_thread(txctx, tmp_path, monkeypatch, kw, burst, numpkts, ring):
     """rawofdm/examples/ofdm_tx.py:37-52 + ofdm_rxtx.py:194-215: make_data -> TX, sender_thread sends
-    bursts of frames, then end of stream; the file holds the frames' samples (times --amp)."""
-    from ofdm_amd import gr, ofdm_rxtx
+    bursts of frames, then end of stream; the file holds the frames' samples (times --amp).
+    ring: every batch counts as large, i.e. goes into the slots of the output ring, is scaled in place
+    and reaches the sink one batch late."""
+    from ofdm_amd import batch, gr, ofdm_rxtx
+    if ring:
+        monkeypatch.setattr(batch.StreamOutput, "RING_MIN_BYTES", 1)
     opt = ro.Options(**kw)
     opt.pause, opt.numpkts, opt.burst = 0.0, numpkts, burst
     tb = gr.top_block()
@@ -604,6 +609,7 @@ def test_tx_driven_like_sender_thread(txctx, tmp_path, kw, burst, numpkts):
     sent = ofdm_rxtx.sender_thread(tx, opt).run()
     tb.wait()
     assert sent >= numpkts and sent % burst == 0
+    assert (tx._output.ring is not None) == ring and (not ring or tx._output.ring.slots == 2)
     p = ro.OfdmParams(opt)
     one = data._data.reshape(opt.size, p.data_tones)
     ref = ro.modulate(p, np.tile(one, (sent, 1)), ro.frame_flags(sent, opt.size)) * 0.5
