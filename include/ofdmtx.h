@@ -43,7 +43,8 @@ extern "C" {
                                  ftw/ftw_ofdm_cmap_cc.cc:97-99, ftw/ftw_ofdm_mapper.cc:61-62) */
 #define OFDMTX_ETOOBIG (-7)   /* batch exceeds the 32-bit row index of the kernels, or the
                                  fixed capacity of an allocation-free entry point           */
-#define OFDMTX_EBUSY (-8)     /* a ragged plan is still running on another stream          */
+#define OFDMTX_EBUSY (-8)     /* not returned any more (launches that share state are ordered
+                                 on the device instead); the value stays reserved             */
 #define OFDMTX_ECOMM (-9)     /* RCCL missing or an RCCL call failed; ofdmtx_last_comm_error() */
 
 /* plan flags */
@@ -168,10 +169,10 @@ int ofdmtx_plan_uniform(ofdmtx_ctx *ctx, uint64_t n_pkts, int regime, uint32_t p
  * payload in the payload buffer; NULL = densely packed in order) are host arrays.
  * A ragged plan owns device-side work counters from which the waves of ofdmtx_tx /
  * ofdmtx_modulate / ofdmtx_encode_bits draw packets (each kernel leaves them at zero when it
- * ends): the same ragged plan must not run in two launches at once.  Launches on ONE stream are
- * ordered and always fine; a launch on a different stream while the previous one has not finished
- * returns OFDMTX_EBUSY (checked on the host with an event recorded behind every launch) -- use one
- * plan per stream.  Uniform plans have no such limit.
+ * ends): the same ragged plan cannot run in two launches at once.  Launches on ONE stream are
+ * ordered anyway; a launch on a different stream than the plan's previous launch is made to start
+ * behind it (an event recorded behind every launch, waited for on the device) -- for launches that
+ * really overlap use one plan per stream.  Uniform plans have no such limit.
  * Lifetime: a plan must stay alive until the launches that use it have finished.
  * ofdmtx_plan_destroy waits for the last launch of a ragged plan before it frees the plan's device
  * tables; uniform plans own no device memory. */
@@ -253,9 +254,10 @@ int ofdmtx_tx(ofdmtx_ctx *ctx, const ofdmtx_plan *plan, const uint8_t *d_payload
  * iq_capacity = complex samples d_iq can hold: if the batch needs more, nothing is written and
  * OFDMTX_EINVAL is returned with *n_samples set to the need.  *n_samples (may be NULL) receives the
  * samples written.  The call waits on `stream` once (the plan totals come back to the host) and
- * returns with the transmit kernel enqueued.  Every call on a GPU uses that GPU's one array: calls
- * that overlap on one GPU (two host threads, or a second call on another stream before the first
- * call's kernel has finished) race -- serialise them. */
+ * returns with the transmit kernel enqueued.  Every call on a GPU uses that GPU's one array, so the
+ * library orders them: the host part runs under a lock per GPU, and a call on another stream than
+ * the previous call's is made to start behind that call's kernels (an event wait on the device,
+ * not a refusal).  Calls from other PROCESSES on the same GPU have arrays of their own. */
 #define OFDMTX_STATIC_MAX_PKTS 65536u
 int ofdmtx_tx_ragged_static(ofdmtx_ctx *ctx, uint64_t n_pkts, const uint8_t *d_regimes,
                             const uint32_t *d_payload_len, const uint64_t *d_payload_off,

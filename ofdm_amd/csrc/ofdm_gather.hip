@@ -15,7 +15,29 @@
 #include <mutex>
 #include <new>
 
+#include <hip/hip_runtime.h>
+
+// The seven entry points used, declared from RCCL's header where it is installed and by hand (the
+// NCCL 2 ABI: opaque communicator, 128-byte id, int-sized enums) where it is not, so that the
+// library builds on machines without the RCCL development files and answers OFDMTX_ECOMM there.
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+extern "C" {
+#define NCCL_UNIQUE_ID_BYTES 128
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0, ncclUint8 = 1, ncclInt32 = 2, ncclFloat32 = 7, ncclFloat = 7 } ncclDataType_t;
+ncclResult_t ncclGetUniqueId(ncclUniqueId *id);
+ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId id, int rank);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+ncclResult_t ncclSend(const void *buf, size_t count, ncclDataType_t type, int peer, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclRecv(void *buf, size_t count, ncclDataType_t type, int peer, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclGroupStart(void);
+ncclResult_t ncclGroupEnd(void);
+}
+#endif
 
 #include "ofdm_common.h"
 

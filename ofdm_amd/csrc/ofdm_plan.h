@@ -7,6 +7,7 @@
 
 #include <stdint.h>
 
+#include <mutex>
 #include <vector>
 
 #include "ofdm_common.h"
@@ -148,14 +149,17 @@ struct ofdmtx_plan {
     uint32_t tx_u_words;   // ... for the scrambled words of the longest packet (payload input)
     uint32_t tx_m_words;   // ... for the message words of the longest packet (message input)
     uint32_t max_sym_rows; // largest n_sym + 1 of the plan
-    // Ragged plans share their device work counters between launches: an event recorded behind
-    // every launch tells whether the previous one (on `last_stream`) has finished.
+    // Ragged plans share their device work counters between launches: an event is recorded behind
+    // every launch, and a launch on another stream than the previous one is made to wait for it
+    // (on the device).  launch_lock covers claim -> enqueue -> mark on the host.
     mutable hipEvent_t busy_ev = nullptr;
     mutable hipStream_t last_stream = nullptr;
     mutable bool launched = false;
+    mutable std::mutex launch_lock;
 };
 
-// ofdmtx.hip: OFDMTX_EBUSY if a ragged plan's previous launch is still running on another stream;
-// mark_launched records the event behind a launch just enqueued on `st`.
+// ofdmtx.hip: claim orders a launch about to be enqueued on `st` behind the plan's previous launch
+// when that ran on another stream (uniform plans: nothing to do); mark_launched records the event
+// behind the launch just enqueued.  Call both under pl->launch_lock.
 int ofdmtx_plan_claim(const ofdmtx_plan *pl, hipStream_t st);
 int ofdmtx_plan_mark_launched(const ofdmtx_plan *pl, hipStream_t st);

@@ -19,6 +19,7 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <mutex>
 #include <new>
 #include <utility>
 #include <vector>
@@ -65,6 +66,19 @@ struct StaticLayout {
     static constexpr size_t total = out + 256;
 };
 static __device__ __align__(256) unsigned char g_static_area[StaticLayout::total];    // 6.6 MB
+
+// Every context on a device shares that device's copy of the area, so calls of
+// ofdmtx_tx_ragged_static are ordered per DEVICE: the host part runs under the device's lock, and
+// an event recorded behind every call's kernels makes a call on another stream start behind them.
+// The events are made by ofdmtx_create (the entry point itself creates nothing).
+struct StaticGuard {
+    std::mutex lock;
+    hipEvent_t done = nullptr;
+    hipStream_t last = nullptr;
+    bool launched = false;
+};
+constexpr int MAX_DEVICES = 64;
+StaticGuard g_static_guard[MAX_DEVICES];
 
 // Work counters of a ragged plan: ctr[0] is the next packet to draw, ctr[1] counts the waves
 // that have left the packet loop.  The last wave out puts both back to zero, so a launch finds
@@ -1655,7 +1669,7 @@ const char *ofdmtx_strerror(int code)
     case OFDMTX_ENOMEM: return "out of memory";
     case OFDMTX_ESHAPE: return "block shape not supported (802.11a needs 48 data carriers, 64-point FFT)";
     case OFDMTX_ETOOBIG: return "batch too large for one launch";
-    case OFDMTX_EBUSY: return "ragged plan still running on another stream";
+    case OFDMTX_EBUSY: return "busy (reserved; not returned)";
     case OFDMTX_ECOMM: return "RCCL not available or an RCCL call failed";
     default: return "unknown error";
     }
@@ -1749,6 +1763,11 @@ int ofdmtx_create(int device, ofdmtx_ctx **out)
     if (e == hipSuccess) e = hipHostMalloc(&c->h_pinned, 256, hipHostMallocDefault);
     // this device's copy of the static work area (the device is current: hipSetDevice above)
     if (e == hipSuccess) e = hipGetSymbolAddress(reinterpret_cast<void **>(&c->d_static), HIP_SYMBOL(g_static_area));
+    if (e == hipSuccess && device >= 0 && device < MAX_DEVICES) {
+        StaticGuard &g = g_static_guard[device];
+        std::lock_guard<std::mutex> guard(g.lock);
+        if (!g.done) e = hipEventCreateWithFlags(&g.done, hipEventDisableTiming);
+    }
     if (e == hipSuccess) e = hipMemcpy(c->d_scr, OFDMTX_SCR_WORD, sizeof(OFDMTX_SCR_WORD), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(c->d_lut, lut, sizeof(lut), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(c->d_pre, OFDMTX_PREAMBLE, sizeof(OFDMTX_PREAMBLE), hipMemcpyHostToDevice);
@@ -2270,13 +2289,9 @@ int ofdmtx_plan_get_layout(const ofdmtx_plan *pl, uint64_t *plcp_off, uint64_t *
 
 int ofdmtx_plan_claim(const ofdmtx_plan *pl, hipStream_t st)
 {
-    if (pl->pp.uniform || !pl->launched || st == pl->last_stream) return OFDMTX_OK;
-    const hipError_t e = hipEventQuery(pl->busy_ev);
-    if (e == hipErrorNotReady) return OFDMTX_EBUSY;
-    if (e != hipSuccess) {
-        ofdmtx_g_last_hip = (int)e;
-        return OFDMTX_EHIP;
-    }
+    if (pl->pp.uniform || !pl->launched || !pl->busy_ev || st == pl->last_stream) return OFDMTX_OK;
+    // the previous launch still draws packets from the plan's counters: this one starts behind it
+    HIPCHK(hipStreamWaitEvent(st, pl->busy_ev, 0));
     return OFDMTX_OK;
 }
 
@@ -2310,6 +2325,7 @@ int ofdmtx_encode_bits(ofdmtx_ctx *ctx, const ofdmtx_plan *pl, const uint8_t *d_
     HIPCHK(hipSetDevice(ctx->device));
     const int grid = grid_for(ctx, pl->pp.n_pkts, ENC_WAVES, 8);
     hipStream_t st = (hipStream_t)stream;
+    std::lock_guard<std::mutex> guard(pl->launch_lock);
     if (int rc = ofdmtx_plan_claim(pl, st)) return rc;
     const PlanParams &pp = pl->pp;
     const DevTables tab = ctx->tables();
@@ -2347,6 +2363,7 @@ template <bool FROM_MSG>
 static int launch_tx(ofdmtx_ctx *ctx, const ofdmtx_plan *pl, const uint8_t *d_in, float2 *mapped, float2 *pilot_tap,
                      float2 *cmap_tap, float2 *iq, hipStream_t st)
 {
+    std::lock_guard<std::mutex> guard(pl->launch_lock);
     if (int rc = ofdmtx_plan_claim(pl, st)) return rc;
     // one chunk: the scrambled / message words share the staging area; several chunks: they need
     // a region of their own
@@ -2473,8 +2490,24 @@ int ofdmtx_tx_ragged_static(ofdmtx_ctx *ctx, uint64_t n_pkts, const uint8_t *d_r
     if (!plan_modes_ok(pilot_mode, flags)) return OFDMTX_EINVAL;
     if (n_pkts > OFDMTX_STATIC_MAX_PKTS) return OFDMTX_ETOOBIG;          // the static tables hold no more
     if (n_pkts == 0) return OFDMTX_OK;
+    if (ctx->device < 0 || ctx->device >= MAX_DEVICES || !g_static_guard[ctx->device].done) return OFDMTX_EINVAL;
     HIPCHK(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
+    // one call at a time per device on the host; on the device, behind the previous call's kernels
+    StaticGuard &guard = g_static_guard[ctx->device];
+    std::lock_guard<std::mutex> host_order(guard.lock);
+    if (guard.launched && st != guard.last) HIPCHK(hipStreamWaitEvent(st, guard.done, 0));
+    struct MarkDone {                                                    // whatever this call enqueued is what the next one waits for
+        StaticGuard &g;
+        hipStream_t st;
+        ~MarkDone()
+        {
+            if (hipEventRecord(g.done, st) == hipSuccess) {
+                g.last = st;
+                g.launched = true;
+            }
+        }
+    } mark_done{guard, st};
     uint8_t *base = ctx->d_static;                                       // never the array's name: see ofdmtx_create
     PlanBuildBufs b;
     b.recs = reinterpret_cast<PktRec *>(base + StaticLayout::recs);

@@ -200,28 +200,32 @@ def test_log_files_of_the_flowgraph(txctx, tmp_path, monkeypatch):
 # ------------------------------------------------------------------ guard rails
 
 def test_ragged_plan_on_a_second_stream_while_busy(txctx):
-    """The work counters of a ragged plan are shared by its launches: a launch on another stream
-    while the previous one still runs must be refused, not raced."""
+    """The work counters of a ragged plan are shared by its launches: a launch on another stream while the
+    previous one still runs is ordered behind it on the device (not refused, not raced) -- both launches
+    produce the batch."""
     rng = np.random.default_rng(40)
     n = 200000
     regimes = rng.integers(1, 9, n).astype(np.uint8)
     lens = rng.integers(200, 1500, n).astype(np.uint32)
     plan = txctx.plan_ragged(regimes, lens)
-    payloads = torch.zeros(int(lens.sum()), dtype=torch.uint8, device=txctx.device)
-    iq = plan.alloc_iq()
-    plan.tx(payloads, out=iq)                                   # (the first launch of a kernel in a process loads its code)
+    payloads = torch.randint(0, 256, (int(lens.sum()),), dtype=torch.uint8, device=txctx.device)
+    want = plan.tx(payloads)                                    # (the first launch of a kernel in a process loads its code)
     torch.cuda.synchronize()
     side = torch.cuda.Stream(device=txctx.device)
-    plan.tx(payloads, out=iq)                                   # two milliseconds of work
-    with torch.cuda.stream(side):
-        with pytest.raises(_lib.OfdmTxError) as e:
-            plan.tx(payloads, out=iq)
-    assert e.value.code == _lib.EBUSY
-    plan.tx(payloads, out=iq)                                   # same stream: ordered, always accepted
+    a, b, c = plan.alloc_iq(), plan.alloc_iq(), plan.alloc_iq()
+    for t in (a, b, c):
+        t.zero_()
     torch.cuda.synchronize()
+    plan.tx(payloads, out=a)                                    # two milliseconds of work
     with torch.cuda.stream(side):
-        plan.tx(payloads, out=iq)                               # idle plan: any stream
+        plan.tx(payloads, out=b)                                # another stream, the first launch still running
+        msg = plan.encode_bits(payloads)                        # the bit chain draws from counters of the same plan
+    plan.tx(payloads, out=c)                                    # and back on the first stream
     torch.cuda.synchronize()
+    for t in (a, b, c):
+        assert torch.equal(t.view(torch.float32), want.view(torch.float32))
+    assert torch.equal(plan.modulate(msg).view(torch.float32), want.view(torch.float32))
+    del a, b, c, msg
     # uniform plans have no shared state
     uni = txctx.plan_uniform(20000, 8, 1500)
     pay = torch.zeros(uni.payload_bytes, dtype=torch.uint8, device=txctx.device)
@@ -337,7 +341,8 @@ def test_spread_output_buffer(txctx):
     del part
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info(txctx.device)
-    assert free0 - free1 < (32 << 20), "the buffer's memory (3 x 64 MiB) did not return to the device"
+    # (the driver keeps some tens of MB of page tables from the search; one lost piece would be 64 MiB more)
+    assert free0 - free1 < (64 << 20), "the buffer's memory (3 x 64 MiB) did not return to the device"
     lib = txctx._lib
     assert lib.ofdmtx_stream_free(txctx._h, C.c_void_p(want.data_ptr())) == _lib.EINVAL
     ptr = C.c_void_p()

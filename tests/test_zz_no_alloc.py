@@ -30,10 +30,15 @@ def test_static_entry_point_matches_plan_and_tx(txctx):
         want = plan.tx(payloads)
         out.fill_(float("nan"))
         torch.cuda.synchronize()
-        mem_before = torch.cuda.memory_allocated(dev)
+        # what the DRIVER says is free on the device (hipMemGetInfo), not what torch's allocator has handed
+        # out: a hipMalloc or hipFree inside the library would show here.  (The first launch of a kernel in
+        # a process loads its code object, so the first round is not held to it.)
+        free_before, _ = torch.cuda.mem_get_info(dev)
         got_n = txctx.tx_ragged_static(regimes, lens, payloads, out, pilot_start=pilot_start, flags=flags, amp=amp)
         torch.cuda.synchronize()
-        assert torch.cuda.memory_allocated(dev) == mem_before
+        free_after, _ = torch.cuda.mem_get_info(dev)
+        if n != 3000:
+            assert free_after == free_before, "device memory changed by %d bytes across the call" % (free_before - free_after)
         assert got_n == plan.n_samples
         assert torch.equal(out[:got_n].view(torch.float32), want.view(torch.float32))
         assert bool(torch.isnan(out[got_n:got_n + 4096].real).all())          # nothing written past the batch
@@ -62,3 +67,32 @@ def test_static_entry_point_limits(txctx):
     want = txctx.plan_ragged(regimes, lens).tx(payloads)
     torch.cuda.synchronize()
     assert torch.equal(big[:got].view(torch.float32), want.view(torch.float32))
+
+
+def test_static_entry_point_calls_on_two_streams_are_ordered(txctx):
+    """All calls on a GPU share one work area.  A second call on another stream, issued while the first
+    call's kernel is still running (and through a second context), is ordered behind it by the library:
+    both batches come out right."""
+    from ofdm_amd.batch import TxContext
+    dev = txctx.device
+    rng = np.random.default_rng(79)
+    other = TxContext(dev.index)
+    side = torch.cuda.Stream(device=dev)
+    big = batch(rng, 60000, dev)
+    small = batch(rng, 500, dev)
+    want_big = txctx.plan_ragged(big[0], big[1], pilot_start=5).tx(big[2])
+    want_small = txctx.plan_ragged(small[0], small[1], pilot_start=9).tx(small[2])
+    out_big = torch.zeros(want_big.numel(), dtype=torch.complex64, device=dev)
+    out_small = torch.zeros(want_small.numel(), dtype=torch.complex64, device=dev)
+    torch.cuda.synchronize()
+    for _ in range(3):
+        n_big = txctx.tx_ragged_static(big[0], big[1], big[2], out_big, pilot_start=5)        # ~1 ms of kernel
+        with torch.cuda.stream(side):
+            n_small = other.tx_ragged_static(small[0], small[1], small[2], out_small, pilot_start=9)
+        torch.cuda.synchronize()
+        assert n_big == want_big.numel() and n_small == want_small.numel()
+        assert torch.equal(out_big.view(torch.float32), want_big.view(torch.float32))
+        assert torch.equal(out_small.view(torch.float32), want_small.view(torch.float32))
+        out_big.zero_()
+        out_small.zero_()
+    other.close()
