@@ -67,6 +67,18 @@ __device__ __forceinline__ void butterfly(v2f &a, v2f &b)
     } else if constexpr (T == 8) {
         a = add_j(t, b);
         b = sub_j(t, b);
+    } else if constexpr (T == 4) {
+        // w = (1 + j) / sqrt 2:  w b = h (b + j b), the factor folded into the two multiply-adds
+        const v2f h = {0.70710678118654752440f, 0.70710678118654752440f};
+        const v2f u = add_j(b, b);
+        a = __builtin_elementwise_fma(h, u, t);
+        b = __builtin_elementwise_fma(-h, u, t);
+    } else if constexpr (T == 12) {
+        // w = (-1 + j) / sqrt 2:  w b = -h (b - j b)
+        const v2f h = {0.70710678118654752440f, 0.70710678118654752440f};
+        const v2f u = sub_j(b, b);
+        a = __builtin_elementwise_fma(-h, u, t);
+        b = __builtin_elementwise_fma(h, u, t);
     } else {
         const v2f w = cmul_s(b, (v2f){W32C[T], W32S[T]});
         a = t + w;
@@ -141,10 +153,23 @@ constexpr float raw_tw_factor() { return L != 64 ? 1.f : (M == 16 ? 5.656854249f
 // stores the rows with 16 bytes per lane, consecutive over the lanes -- output sample i of a row is
 // time sample (i - cp) mod N (gr-digital ofdm_cyclic_prefixer, rawofdm/src/python/raw_ofdm_mod.py:47).
 // All lanes of the wave must call it (wave-level hand-overs inside).
+// s_tw1 (L == 64 only): the first step's twiddles W_N^{A b n3} as a V x V image [n3][b], so that the
+// 16 (or 8) different values a wave reads at once lie side by side -- out of the full table the same
+// read strides over it by 32 n3 bytes and meets 2- to 8-way bank conflicts.
+template <int L, int M>
+constexpr int raw_tw1_size() { return L == 64 ? M * M : 1; }
+template <int L, int M>
+__device__ __forceinline__ void raw_tw1_fill(v2f *s_tw1, const v2f *s_tw, int tid, int n_thr)
+{
+    if constexpr (L == 64) {
+        constexpr int V = M, A = 64 / V, N = L * M;
+        for (int i = tid; i < V * V; i += n_thr) s_tw1[i] = s_tw[(A * (i % V) * (i / V)) & (N - 1)];
+    }
+}
 template <int L, int M>
 __device__ __forceinline__ void raw_transform_store(bool active, int t, int lane, uint32_t row, v2f (&x)[M], v2f *T,
-                                                    const v2f *T_wave, const v2f *s_tw, uint32_t n, uint32_t cp,
-                                                    float2 *__restrict__ iq)
+                                                    const v2f *T_wave, const v2f *s_tw, const v2f *s_tw1, uint32_t n,
+                                                    uint32_t cp, float2 *__restrict__ iq)
 {
     constexpr int N = L * M, S = L > M ? L : M, SPW = 64 / S, TS = raw_area<L, M>();
     const uint32_t row_len = n + cp;
@@ -165,7 +190,7 @@ __device__ __forceinline__ void raw_transform_store(bool active, int t, int lane
         {
             const int b = lane / A;
 #pragma unroll
-            for (int n3 = 0; n3 < V; n3++) T[n3 * E1 + lane] = cmul(x[n3], s_tw[(A * b * n3) & (N - 1)]);
+            for (int n3 = 0; n3 < V; n3++) T[n3 * E1 + lane] = cmul(x[n3], s_tw1[n3 * V + b]);
         }
         wave_sync();
         const int n3 = lane & (V - 1), a2 = lane / V;
@@ -189,12 +214,31 @@ __device__ __forceinline__ void raw_transform_store(bool active, int t, int lane
             for (int n1 = 0; n1 < A; n1++) x[A * i + n1] = z[n1];
         }
         wave_sync();
-        SEC("t_cp");
+        // ---- rows straight from the registers: x[A i + n1] is time sample Q n1 + 64 i + lane, so every
+        // (i, n1) is 64 consecutive samples = 512 contiguous bytes of the row, 8 bytes per lane; the
+        // samples of the last cp are stored a second time at the row's start (output sample i of a row
+        // is time sample (i - cp) mod N).  Against staging the row in LDS for 16-byte stores (16 LDS
+        // stores and 10 wide LDS loads per symbol, in kernels whose LDS array is busy for 60 % of their
+        // time): bytes -> IQ at N = 1024 0.61 -> 0.575 ms per 2.6 10^5 symbols, N = 512 and the
+        // modulator alone unchanged; the same bits.
+        SEC("t_store");
+        const uint32_t row_w = __shfl(row, 0);
+        if (row_w != ROW_DROPPED) {
+            const __amdgpu_buffer_rsrc_t win = iq_window(iq + (size_t)row_w * row_len);
+            const uint32_t tail = n - cp;
 #pragma unroll
-        for (int i = 0; i < Q / 64; i++)
+            for (int n1 = 0; n1 < A; n1++)
 #pragma unroll
-            for (int n1 = 0; n1 < A; n1++) T[Q * n1 + lane + 64 * i] = x[A * i + n1];
-        wave_sync();
+                for (int i = 0; i < Q / 64; i++) {
+                    const uint32_t sm = (uint32_t)(Q * n1 + 64 * i) + (uint32_t)lane;
+                    const v2f v = x[A * i + n1];
+                    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                    const u32x2 d = {__float_as_uint(v.x), __float_as_uint(v.y)};
+                    __builtin_amdgcn_raw_buffer_store_b64(d, win, (int)((cp + sm) * 8u), 0, RAW_ROW_AUX);
+                    if (sm >= tail) __builtin_amdgcn_raw_buffer_store_b64(d, win, (int)((sm - tail) * 8u), 0, RAW_ROW_AUX);
+                }
+        }
+        return;
     } else {
     if (active && t < L) {
         idft_reg<M>(x);
@@ -269,6 +313,9 @@ k_raw_modulate(RawParams R, const float2 *__restrict__ data, float2 *__restrict_
         s_tw[i] = (v2f){w.x, w.y} * raw_tw_factor<L, M>();
         s_src[i] = R.src[i];
     }
+    __shared__ v2f s_tw1[raw_tw1_size<L, M>()];
+    __syncthreads();
+    raw_tw1_fill<L, M>(s_tw1, s_tw, tid, 64 * W);
     __syncthreads();
 
     const int t = lane % S, slot = lane / S;
@@ -327,8 +374,8 @@ k_raw_modulate(RawParams R, const float2 *__restrict__ data, float2 *__restrict_
                 }
             }
         }
-        raw_transform_store<L, M>(active, t, lane, active ? row : ROW_DROPPED, x, T, s_t + wave * SPW * TS, s_tw, R.n,
-                                  R.cp, iq);
+        raw_transform_store<L, M>(active, t, lane, active ? row : ROW_DROPPED, x, T, s_t + wave * SPW * TS, s_tw, s_tw1,
+                                  R.n, R.cp, iq);
         wave_sync();
     }
 }
@@ -994,7 +1041,7 @@ __device__ __forceinline__ void fused_idx_fixed(uint8_t *row_pad)
 template <int L, int M, int QB>
 __device__ __forceinline__ void fused_modulate_round(const RawParams &R, const uint8_t *irow, const uint32_t (&ioff)[M],
                                                      bool active, int slot, int t, int lane, v2f *T, const v2f *T_wave,
-                                                     const v2f *s_tw, const v2f *s_lut, uint32_t first_frame,
+                                                     const v2f *s_tw, const v2f *s_tw1, const v2f *s_lut, uint32_t first_frame,
                                                      uint32_t first_in_frame, uint32_t syms_here, const SmallDiv &fdiv,
                                                      float2 *__restrict__ iq)
 {
@@ -1014,7 +1061,7 @@ __device__ __forceinline__ void fused_modulate_round(const RawParams &R, const u
 #pragma unroll
     for (int m = 0; m < M; m++) x[bit_reverse(m, M)] = s_lut[irow[ioff[m]]];
     wave_sync();                                              // index bytes read: the areas may be overwritten
-    raw_transform_store<L, M>(active, t, lane, row, x, T, T_wave, s_tw, R.n, R.cp, iq);
+    raw_transform_store<L, M>(active, t, lane, row, x, T, T_wave, s_tw, s_tw1, R.n, R.cp, iq);
     SEC("m_pre");
     // ---- preamble rows of the frames that start in this wave's symbols
     // (gr-digital ofdm_insert_preamble as wired at rawofdm/src/python/raw_ofdm_mod.py:45,50-52)
@@ -1066,7 +1113,12 @@ k_raw_tx(RawParams R, QamTxParams Q, const uint8_t *__restrict__ data, float2 *_
     }
     fused_lut_fill<QB>(s_lut, Q.scale, tid, 64 * W);
     GLut::fill(s_glut, tid, 64 * W);
-    __syncthreads();                                              // the only workgroup barrier
+    __shared__ v2f s_tw1[raw_tw1_size<L, M>()];
+    if constexpr (L == 64) {
+        __syncthreads();
+        raw_tw1_fill<L, M>(s_tw1, s_tw, tid, 64 * W);
+    }
+    __syncthreads();                                              // the last workgroup barrier
 
     // this wave's LDS: SPW symbol areas, then (rounds > 1) the index rows of a pass; with one round
     // per pass the SPW index rows lie at the end of the areas instead (they are in registers before
@@ -1145,7 +1197,7 @@ k_raw_tx(RawParams R, QamTxParams Q, const uint8_t *__restrict__ data, float2 *_
         for (uint32_t sub = 0; sub < rows_here; sub += (uint32_t)SPW) {
             const uint32_t r_in = sub + (uint32_t)slot;
             fused_modulate_round<L, M, QB>(R, idx_wave + (r_in < rows_here ? r_in : sub) * idx_stride, ioff, r_in < rows_here, slot, t, lane, T, T_wave,
-                                           s_tw, s_lut, f0, s0 + sub, rows_here - sub, fdiv, iq);
+                                           s_tw, s_tw1, s_lut, f0, s0 + sub, rows_here - sub, fdiv, iq);
             wave_sync();                                          // the areas are rewritten in the next round
         }
     }

@@ -71,3 +71,19 @@ for rep in range(4):
         t_q = timed(lambda: lib.ofdmtx_raw_qam_tx(h, tx.qambits, tx.nc, tx.np, p.data_tones, nsym, VP(data.data_ptr()), n_frames, VP(vals.data_ptr()), st))
         t_f = timed(lambda: lib.ofdmtx_raw_tx(h, rp, tx.qambits, tx.nc, tx.np, VP(data.data_ptr()), VP(iq.data_ptr()), st))
         print("%-16s modulator %.3f | bit chain %.3f | bytes->IQ %.3f ms" % (name, t_m, t_q, t_f), flush=True)
+
+# the variants' output against the first one's (bytes -> IQ and the modulator)
+ref = None
+for name, lib, h, rp in variants:
+    iq.zero_()
+    lib.ofdmtx_raw_tx(h, rp, tx.qambits, tx.nc, tx.np, VP(data.data_ptr()), VP(iq.data_ptr()), st)
+    a = iq.clone()
+    iq.zero_()
+    lib.ofdmtx_raw_modulate(h, rp, VP(vals_in.data_ptr()), None, VP(iq.data_ptr()), st)
+    b = iq.clone()
+    torch.cuda.synchronize()
+    if ref is None:
+        ref = (a, b)
+    else:
+        print("%-16s max |difference| to %s: bytes->IQ %.3g, modulator %.3g (largest sample %.3g)"
+              % (name, variants[0][0], float((a - ref[0]).abs().max()), float((b - ref[1]).abs().max()), float(ref[0].abs().max())))
