@@ -508,16 +508,29 @@ __device__ __forceinline__ void encode_data_symbols(const uint32_t *U, uint32_t 
 // 64 payload words loaded before the first is used.
 // One round of a packet's payload words, requested ahead of their use: the aligned dwords
 // q[lane + 64 kk], kk < K, of the payload that starts at pp (0 beyond it).
+// A packet's bytes as a buffer resource: aligned dwords from the one that holds the first byte on,
+// as many as hold bytes of the packet -- a load beyond them returns 0 without a compare or a select
+// in the wave's instruction stream, and the address is one 32-bit offset per lane.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t payload_window(const uint8_t *pp, uint32_t pay_len)
+{
+    const uint64_t a = reinterpret_cast<uint64_t>(pp);                   // the same in every lane of the wave
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
+    const uint32_t al = lo & 3u;
+    const uint32_t bytes = (uint32_t)__builtin_amdgcn_readfirstlane((int)((al + pay_len + 3u) & ~3u));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>((((uint64_t)hi << 32) | lo) - al), 0, (int)bytes, 0x00020000);
+}
+
 template <int K>
 struct PayloadAhead {
     uint32_t w[K];
     __device__ __forceinline__ void fetch(const uint8_t *pp, uint32_t pay_len, int lane)
     {
-        const uint32_t al = (uint32_t)(reinterpret_cast<uintptr_t>(pp) & 3u);
-        const uint32_t *q = reinterpret_cast<const uint32_t *>(pp - al);
-        const uint32_t n_pw = (pay_len + 3u) / 4u;
+        const __amdgpu_buffer_rsrc_t win = payload_window(pp, pay_len);
 #pragma unroll
-        for (int kk = 0; kk < K; kk++) w[kk] = (uint32_t)lane + 64u * kk < n_pw ? q[(uint32_t)lane + 64u * kk] : 0u;
+        // (the row's offset goes into the per-lane offset, which the range check covers; the scalar
+        //  offset operand is outside it)
+        for (int kk = 0; kk < K; kk++) w[kk] = __builtin_amdgcn_raw_buffer_load_b32(win, 4 * lane + 256 * kk, 0, 0);
     }
 };
 
@@ -526,7 +539,12 @@ struct PayloadAhead {
 // RAW (plans with OFDMTX_F_RAW_PSDU): the packet's bytes are the whole PSDU -- MPDU and FCS as they go
 // on air, in natural byte order -- so no MAC header is built and no CRC computed; LENGTH is the byte
 // count itself.  Everything behind step 2 is the same code.
-template <int K, bool AHEAD = false, bool RAW = false>
+// FAST: payloads that start on a dword boundary (a branch the whole wave takes together) are staged
+// row by row -- 64 dwords per load, fetched through a buffer resource that answers 0 beyond the
+// packet, stored with immediate offsets -- instead of word by word with compares and selects.  Used
+// where the instruction count sets the time (k_encode_bits: 3 % there); the fused kernel, bound by its
+// stores, keeps the form its register budget was tuned with.
+template <int K, bool AHEAD = false, bool RAW = false, bool FAST = false>
 __device__ __forceinline__ void scramble_packet(const Pkt &k, const RegimeInfo &ri, const DevTables &T,
                                                 const uint8_t *__restrict__ payloads, uint32_t *A, uint32_t *U,
                                                 const uint32_t *s_crc, const uint32_t *s_scr, int lane_in,
@@ -578,6 +596,32 @@ __device__ __forceinline__ void scramble_packet(const Pkt &k, const RegimeInfo &
         const uint32_t *q = reinterpret_cast<const uint32_t *>(pp - al);
         const uint32_t n_pw = n_dw - (HDR - 2u);                             // payload dwords, the last may be partial
         const uint32_t total = n_words + 3u - HDR;                           // words behind the header to write
+        bool staged = false;
+        if constexpr (FAST) {
+            if (__builtin_amdgcn_readfirstlane((int)al) == 0) {
+                staged = true;
+                const __amdgpu_buffer_rsrc_t win = payload_window(pp, k.pay_len);
+                const uint32_t rows = (uint32_t)__builtin_amdgcn_readfirstlane((int)((total + 63u) / 64u));
+                uint32_t *dst = A + HDR + lane;
+                for (uint32_t r0 = 0; r0 < rows; r0 += K) {
+                    uint32_t w[K];
+#pragma unroll
+                    for (int kk = 0; kk < K; kk++) {
+                        if (AHEAD && r0 == 0) w[kk] = ahead->w[kk];
+                        else w[kk] = __builtin_amdgcn_raw_buffer_load_b32(win, 4 * lane + 256 * (int)(r0 + kk), 0, 0);
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < K; kk++) {
+                        if (r0 + kk + 1u < rows) dst[64u * (r0 + kk)] = w[kk];                     // a whole row
+                        else if (r0 + kk < rows && (uint32_t)lane + 64u * (r0 + kk) < total) dst[64u * (r0 + kk)] = w[kk];
+                    }
+                }
+                // the last payload word may hold bytes of whatever follows the packet: cleared by the lane that wrote it
+                const uint32_t part = k.pay_len & 3u;
+                if (part && (uint32_t)lane == ((n_pw - 1u) & 63u)) A[HDR + n_pw - 1u] &= (1u << (8u * part)) - 1u;
+            }
+        }
+        if (!staged)
         for (uint32_t j0 = (uint32_t)lane; j0 < total; j0 += 64u * K) {
             uint32_t lo[K], hi[K];
 #pragma unroll
@@ -682,9 +726,13 @@ __device__ __forceinline__ void encode_packet(const Pkt &k, const RegimeInfo &ri
                                      uint8_t *plcp_out, uint8_t *scr_out, uint8_t *cod_out,
                                      PayloadAhead<8> *ahead = nullptr, const uint8_t *next_pp = nullptr, uint32_t next_len = 0)
 {
-    if constexpr (RAW) scramble_packet<8, false, true>(k, ri, T, payloads, A, U, s_crc, s_scr, lane, plcp_out, scr_out);
-    else if (ahead) scramble_packet<8, true>(k, ri, T, payloads, A, U, s_crc, s_scr, lane, plcp_out, scr_out, ahead, next_pp, next_len);
-    else scramble_packet<8>(k, ri, T, payloads, A, U, s_crc, s_scr, lane, plcp_out, scr_out);
+    // (row-wise staging everywhere but in the 16-QAM r1/2 instantiation, where its few extra registers
+    //  -- 126 -> 129 -- would cost a wave per SIMD: 2.37 -> 2.61 ms per 10^6 packets; with it the headline
+    //  regime runs 1.98 -> 1.92 ms, the others within 1 %)
+    constexpr bool FAST = REGIME != 5;
+    if constexpr (RAW) scramble_packet<8, false, true, FAST>(k, ri, T, payloads, A, U, s_crc, s_scr, lane, plcp_out, scr_out);
+    else if (ahead) scramble_packet<8, true, false, FAST>(k, ri, T, payloads, A, U, s_crc, s_scr, lane, plcp_out, scr_out, ahead, next_pp, next_len);
+    else scramble_packet<8, false, false, FAST>(k, ri, T, payloads, A, U, s_crc, s_scr, lane, plcp_out, scr_out);
 
     SEC("e4_signal");
     // ---- 4. SIGNAL symbol: 48 coded bits, N = 48 first permutation only (pu:245-249)
