@@ -177,18 +177,24 @@ Built build_spread(int device, size_t pieces, int want_parts)
         return (c[0] * WINDOW >= want3) || (parts < 3 && c[1] * WINDOW >= want2);
     };
 
-    while (ok && !enough(want_parts) && W.size() < max_windows) {
+    bool exhausted = false;                                 // the device gave no more memory (less was free than it said)
+    while (ok && !exhausted && !enough(want_parts) && W.size() < max_windows) {
         // ---- one step: STEP_WINDOWS more windows, mapped behind the ones already there
-        const size_t w0 = W.size(), w1 = std::min(max_windows, w0 + STEP_WINDOWS);
+        const size_t w0 = W.size();
+        size_t w1 = std::min(max_windows, w0 + STEP_WINDOWS);
         for (size_t k = w0 * WINDOW; k < w1 * WINDOW && ok; k++) {
             hipMemGenericAllocationHandle_t one;
-            ok = hipMemCreate(&one, PIECE, &prop, 0) == hipSuccess;
-            if (!ok) break;
+            if (hipMemCreate(&one, PIECE, &prop, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                exhausted = true;
+                w1 = k / WINDOW;                            // whole windows only; the pieces behind them are released with the rest
+                break;
+            }
             h.push_back(one);
             ok = hipMemMap(pool + k * PIECE, PIECE, 0, one, 0) == hipSuccess;
             if (ok) n_mapped++;
         }
-        if (!ok) break;
+        if (!ok || w1 == w0) break;
         ok = hipMemSetAccess(win(w0), (w1 - w0) * WINDOW * PIECE, &acc, 1) == hipSuccess;
         if (!ok) break;
         // ---- every new window with itself.  A window that lies in one part takes the one-part time; on

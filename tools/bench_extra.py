@@ -69,7 +69,7 @@ def main():
     ctx = TxContext(0)
     dev = ctx.device
     if a.placement == "spread":
-        mem, spread = ctx.alloc_spread(int(a.arena_gb * 1e9) // 8 * 8)
+        mem, spread = ctx.alloc_spread(int(a.arena_gb * 1e9) // 8 * 8, parts=3)
         if spread:
             ARENA["mem"], ARENA["mode"] = mem, "spread"
     if a.only == "qam":
