@@ -3,9 +3,10 @@ the FTW transmitter one bit at a time in plain Python, keeping the reference's C
 scatter loops for the permutations, the sliding-offset loops of the puncturer, a shift register
 for the encoder -- where the numpy oracle (oracle/ftw_oracle.py) uses closed forms (index masks,
 shifted XORs, inverse permutations).  Agreement of the two pins the closed forms; its run time
-also shows the order of magnitude of a per-bit Python transmitter (bench.py does not use it).
+also shows the order of magnitude of a per-bit Python transmitter, which bench.py reports beside
+the C port's as cpu_baseline.config1_py_refshaped (one packet, outside every timed region).
 
-Only tests/ may import this module.  Citations: pu = ftw_80211_ofdm_tx/src/examples/
+Only tests/ and the cpu_baseline leg of bench.py may import this module.  Citations: pu = ftw_80211_ofdm_tx/src/examples/
 ftw_packet_utils.py of the reference.
 """
 import zlib
