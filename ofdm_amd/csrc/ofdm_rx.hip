@@ -1,6 +1,6 @@
 // libofdmtx, loop-back verifier: a receiver for the noiseless frames the transmit kernels
 // produce, written from IEEE 802.11-2007 clause 17 (not from the transmitter's code paths):
-//   k_rx_demod  : per packet, per OFDM symbol: 64-point DFT of the samples behind the cyclic
+//   k_rx_demod  : per packet, per OFDM symbol: 64-point DFT (8 x 8) of the samples behind the cyclic
 //                 prefix, nearest-point decision against the constellation table, pilot and
 //                 null-carrier checks, de-interleaving (17.3.5.6, equations 17-18 / 17-19)
 //                 -> the packet's hard coded bits in transmit order (the layout of the `coded`
@@ -45,29 +45,95 @@ __device__ __forceinline__ float expected_pilot(const PlanParams &P, const DevTa
     return bin == 21 ? -p : p;                                    // +21 carries -p
 }
 
+// ---- 17.3.5.6 inverted for the NB bits one data carrier holds.  Equations 17-18 / 17-19 with N = 48 NB
+// coded bits per symbol and s = max(NB / 2, 1) say: the interleaver writes the symbol's coded bits into
+// 16 columns, row by row, and reads column by column, rotating each run of s bits by (column mod s).
+// Backwards, for data carrier `code` = 3 c + d (c = column 0..15): the I bits and the Q bits are each
+// rotated right by c mod s, and bit t of the result is coded bit 16 (d NB + t) + c of the symbol --
+// bit c of the 16-bit unit number d NB + t.  `hw0` = 16-bit units of the packet before this symbol;
+// the ones are ORed into the packet's MSB-first words.
+template <int NB>
+__device__ __forceinline__ void deinterleave_carrier(uint32_t *W, uint32_t hw0, uint32_t code, uint32_t best)
+{
+    constexpr uint32_t SG = NB / 2 > 1 ? NB / 2 : 1, MASK = (1u << SG) - 1u;
+    const uint32_t c = (code * 43u) >> 7;                                  // code / 3, code < 48
+    uint32_t v = best;
+    if (SG > 1) {
+        const uint32_t rot = SG == 2 ? (c & 1u) : c - 3u * ((c * 11u) >> 5);           // c mod s, c < 16
+        const uint32_t hi = v >> SG, lo = v & MASK;
+        v = ((((hi >> rot) | (hi << (SG - rot))) & MASK) << SG) | (((lo >> rot) | (lo << (SG - rot))) & MASK);
+    }
+    const uint32_t first = hw0 + (code - 3u * c) * NB;
+#pragma unroll
+    for (int t = 0; t < NB; t++) {
+        if ((v >> (NB - 1 - t)) & 1u) {
+            const uint32_t hw = first + (uint32_t)t;
+            atomicOr(&W[hw >> 1], 1u << (((~hw & 1u) << 4) + 15u - c));
+        }
+    }
+}
+
+// index of the level nearest to x: the low three bits of each distance are replaced by the level's number, so
+// that one unsigned minimum finds both (distances are not negative: their bit patterns order as integers)
+__device__ __forceinline__ uint32_t nearest_level(float x, const float (&lv)[8])
+{
+    uint32_t m = 0xFFFFFFFFu;
+#pragma unroll
+    for (int a = 0; a < 8; a++) m = min(m, (__float_as_uint(fabsf(x - lv[a])) & ~7u) | (uint32_t)a);
+    return m & 7u;
+}
+
+constexpr int RX_TG = 72;              // float2 per symbol in the transposition layout (8 rows x 9)
+
+// One wavefront per packet, eight OFDM symbols at a time, eight lanes per symbol (lane = 8 g + l).
+// The forward DFT of a symbol is the inverse one with real and imaginary parts exchanged on the
+// way in and on the way out; as 8 x 8: lane l transforms the samples l + 8 m over m, multiplies by
+// W64^{l p}, the eight lanes of the symbol transpose through LDS, lane p transforms over l and
+// holds the bins 8 q + p, q = 0..7.
 template <bool UNIFORM>
-__global__ void __launch_bounds__(64 * RX_WAVES)
+__global__ void __launch_bounds__(64 * RX_WAVES, 5)
 k_rx_demod(PlanParams P, DevTables T, const float2 *__restrict__ iq, uint8_t *__restrict__ coded,
            uint32_t *__restrict__ status, uint32_t wave_words)
 {
     extern __shared__ uint32_t s_rxw[];                   // per wave: the packet's coded bits, MSB-first words
-    __shared__ float2 s_w[64];                            // e^{-j 2 pi m / 64}
+    __shared__ v2f s_tw[64];                              // W64^{l p} / (8 amp) at 8 p + l
     __shared__ float2 s_lut[LUT_SIZE];
-    __shared__ float2 s_x[RX_WAVES][64];
+    __shared__ v2f s_t[RX_WAVES][8 * RX_TG];
+    __shared__ int s_code[64];                            // what each FFT bin carries
+    __shared__ int s_sep[2];                              // the 16-QAM / 64-QAM table is a product I[hi] x Q[lo]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < 64; i += 64 * RX_WAVES) s_w[i] = make_float2(T.tw64[i].x, -T.tw64[i].y);
-    for (int i = tid; i < LUT_SIZE; i += 64 * RX_WAVES) s_lut[i] = T.lut[i];
-    __syncthreads();
-
-    uint32_t *W = s_rxw + (size_t)wave * wave_words;
-    const bool swap_iq = (P.flags & OFDMTX_F_SWAPIQ) != 0;
-    const uint32_t pre_rows = (P.flags & OFDMTX_F_PREAMBLE)
-                                  ? ((P.flags & (OFDMTX_F_PNC_A | OFDMTX_F_PNC_B)) ? 6u : 4u) : 0u;
+    const int l = lane & 7, g = lane >> 3;
     // the transmitter's rows are (amp / 8) * sum_k X[k] e^{+j 2 pi k n / 64}: the forward DFT
     // returns 8 * amp * X[k]
     const float inv = 1.0f / (8.0f * P.amp);
-    const int code = bin_code(lane);                      // what this lane's FFT bin carries
+    for (int i = tid; i < 64; i += 64 * RX_WAVES) {
+        const float2 w = T.tw64[((i & 7) * (i >> 3)) & 63];
+        s_tw[i] = (v2f){w.x * inv, w.y * inv};
+        s_code[i] = bin_code(i);
+    }
+    for (int i = tid; i < LUT_SIZE; i += 64 * RX_WAVES) s_lut[i] = T.lut[i];
+    if (tid < 2) s_sep[tid] = 1;
+    __syncthreads();
+    // A table whose point (a << h) | b is (I[a], Q[b]) is searched per axis: 2 * 2^h distances
+    // instead of 4^h, the same nearest point.  The standard tables are of that kind (17.3.5.7: the
+    // first half of a carrier's bits selects I, the second half Q); a caller's own table need not be.
+    for (int i = tid; i < 16 + 64; i += 64 * RX_WAVES) {
+        const int big = i >= 16, off = big ? 64 : 16, h = big ? 3 : 2, idx = big ? i - 16 : i;
+        const float2 c = s_lut[off + idx];
+        if (c.x != s_lut[off + (idx >> h << h)].x || c.y != s_lut[off + (idx & ((1 << h) - 1))].y) s_sep[big] = 0;
+    }
+    __syncthreads();
+
+    uint32_t *W = s_rxw + (size_t)wave * wave_words;
+    v2f *buf = s_t[wave];
+    float2 sig[2];                                        // the SIGNAL symbol's two points, in scalar registers
+    for (int i = 0; i < 2; i++)
+        sig[i] = make_float2(__uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_lut[LUT_PM1 + i].x))),
+                             __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_lut[LUT_PM1 + i].y))));
+    const bool swap_iq = (P.flags & OFDMTX_F_SWAPIQ) != 0;
+    const uint32_t pre_rows = (P.flags & OFDMTX_F_PREAMBLE)
+                                  ? ((P.flags & (OFDMTX_F_PNC_A | OFDMTX_F_PNC_B)) ? 6u : 4u) : 0u;
 
     for (uint32_t p = blockIdx.x * RX_WAVES + wave; p < P.n_pkts; p += gridDim.x * RX_WAVES) {
         const Pkt k = load_pkt<UNIFORM>(P, p);
@@ -77,51 +143,100 @@ k_rx_demod(PlanParams P, DevTables T, const float2 *__restrict__ iq, uint8_t *__
         const uint32_t n_words = (msg_len + 3u) / 4u;
         for (uint32_t w = lane; w < n_words + 1u; w += 64) W[w] = 0u;
         uint32_t bad = 0;
+        // the packet's DATA table in registers: by axis where it is a product (unused levels out of reach);
+        // BPSK / QPSK: the points themselves, (lv_i[i], lv_q[i])
+        const int h = ri.n_bpsc >> 1;
+        const bool by_axis = ri.n_bpsc >= 4 && s_sep[ri.n_bpsc == 6];
+        float lv_i[8], lv_q[8];
+#pragma unroll
+        for (int a = 0; a < 8; a++) {
+            const bool used = by_axis ? a < (1 << h) : a < (1 << ri.n_bpsc) && ri.n_bpsc <= 2;
+            const float2 ci = s_lut[ri.lut_off + (by_axis ? a << h : a)], cq = s_lut[ri.lut_off + a];
+            lv_i[a] = used ? ci.x : 1.0e18f;
+            lv_q[a] = used ? cq.y : 1.0e18f;
+        }
         wave_sync();
 
-        for (uint32_t s = 0; s <= k.n_sym; s++) {
-            float2 x = iq[(row0 + s) * SYM_LEN + 16u + (uint32_t)lane];       // behind the cyclic prefix
-            if (swap_iq) x = make_float2(x.y, x.x);
-            s_x[wave][lane] = x;
-            wave_sync();
-            float ar = 0.f, ai = 0.f;
-#pragma unroll 8
-            for (int n = 0; n < 64; n++) {
-                const float2 v = s_x[wave][n], w = s_w[(lane * n) & 63];
-                ar += v.x * w.x - v.y * w.y;
-                ai += v.x * w.y + v.y * w.x;
+        const uint32_t rows = k.n_sym + 1u;               // SIGNAL and the DATA symbols
+        // a group's samples are fetched while the group before it is decided: (im, re) in; an
+        // I/Q-exchanged transmission is exchanged back first, which leaves (re, im)
+        const float2 *src = iq + row0 * SYM_LEN + 16u + (uint32_t)(g * SYM_LEN + l);     // behind the cyclic prefix
+        float2 nx[8];
+        if ((uint32_t)g < rows) {
+#pragma unroll
+            for (int m = 0; m < 8; m++) nx[m] = src[8 * m];
+        }
+        for (uint32_t r0 = 0; r0 < rows; r0 += 8u) {
+            const uint32_t s = r0 + (uint32_t)g;
+            const bool active = s < rows;
+            v2f x[8];
+            if (active) {
+#pragma unroll
+                for (int m = 0; m < 8; m++) x[m] = swap_iq ? (v2f){nx[m].x, nx[m].y} : (v2f){nx[m].y, nx[m].x};
             }
-            ar *= inv;
-            ai *= inv;
-            if (code >= 0) {
-                // nearest constellation point; SIGNAL is BPSK whatever the rate (17.3.4)
+            if (s + 8u < rows) {
+                const float2 *next = src + (size_t)(r0 + 8u) * SYM_LEN;
+#pragma unroll
+                for (int m = 0; m < 8; m++) nx[m] = next[8 * m];
+            }
+            if (active) {
+                idft8(x);
+#pragma unroll
+                for (int q = 0; q < 8; q++) x[q] = cmul(x[q], s_tw[8 * q + l]);
+#pragma unroll
+                for (int q = 0; q < 8; q++) buf[g * RX_TG + 9 * q + l] = x[q];
+            }
+            wave_sync();
+            if (active) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) x[i] = buf[g * RX_TG + 9 * l + i];
+                idft8(x);                                 // x[q] = (im, re) of bin 8 q + l
+
+                // SIGNAL is BPSK whatever the rate (17.3.4)
                 const int nb = s == 0 ? 1 : ri.n_bpsc;
                 const int off = s == 0 ? LUT_PM1 : ri.lut_off;
-                int best = 0;
-                float best_d = 3.0e38f;
-                for (int i = 0; i < (1 << nb); i++) {
-                    const float2 c = s_lut[off + i];
-                    const float d = (ar - c.x) * (ar - c.x) + (ai - c.y) * (ai - c.y);
-                    if (d < best_d) { best_d = d; best = i; }
-                }
-                // 17.3.5.6: position j of the symbol came from coded bit k
-                const uint32_t N = s == 0 ? 48u : (uint32_t)ri.n_cbps;
-                const uint32_t sg = nb / 2 > 1 ? (uint32_t)nb / 2u : 1u;
-                const uint32_t base = s == 0 ? 0u : 48u + (s - 1u) * N;
-                for (int t = 0; t < nb; t++) {
-                    const uint32_t j = (uint32_t)code * (uint32_t)nb + (uint32_t)t;
-                    const uint32_t i = sg * (j / sg) + (j + 16u * j / N) % sg;        // (17-18)
-                    const uint32_t kk = 16u * i - (N - 1u) * (16u * i / N);           // (17-19)
-                    if ((best >> (nb - 1 - t)) & 1) {
-                        const uint32_t g = base + kk;
-                        atomicOr(&W[g >> 5], 1u << (31u - (g & 31u)));
+                const uint32_t hw0 = s == 0 ? 0u : 3u + (s - 1u) * (uint32_t)ri.n_cbps / 16u;
+                const uint32_t pidx = (k.pilot_base + s) % 127u;
+                const bool per_axis = by_axis && s != 0;
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const int bin = 8 * q + l, code = s_code[bin];
+                    const float ar = x[q].y, ai = x[q].x;
+                    if (code >= 0) {
+                        // nearest constellation point
+                        uint32_t best = 0;
+                        if (per_axis) {
+                            best = (nearest_level(ar, lv_i) << h) | nearest_level(ai, lv_q);
+                        } else if (nb <= 2) {
+                            float best_d = 3.0e38f;
+#pragma unroll
+                            for (int i = 0; i < 4; i++) {
+                                const float2 c = s == 0 ? (i < 2 ? sig[i] : make_float2(1.0e18f, 1.0e18f))
+                                                        : make_float2(lv_i[i], lv_q[i]);
+                                const float d = (ar - c.x) * (ar - c.x) + (ai - c.y) * (ai - c.y);
+                                if (d < best_d) { best_d = d; best = (uint32_t)i; }
+                            }
+                        } else {
+                            float best_d = 3.0e38f;
+                            for (int i = 0; i < (1 << nb); i++) {
+                                const float2 c = s_lut[off + i];
+                                const float d = (ar - c.x) * (ar - c.x) + (ai - c.y) * (ai - c.y);
+                                if (d < best_d) { best_d = d; best = (uint32_t)i; }
+                            }
+                        }
+                        switch (nb) {
+                        case 1: deinterleave_carrier<1>(W, hw0, (uint32_t)code, best); break;
+                        case 2: deinterleave_carrier<2>(W, hw0, (uint32_t)code, best); break;
+                        case 4: deinterleave_carrier<4>(W, hw0, (uint32_t)code, best); break;
+                        default: deinterleave_carrier<6>(W, hw0, (uint32_t)code, best); break;
+                        }
+                    } else if (code == -1) {
+                        if (ar * ar + ai * ai > RX_TOL * RX_TOL) bad |= OFDMTX_RX_NULLS;
+                    } else {
+                        const float e = expected_pilot(P, T, bin, pidx);
+                        if ((ar - e) * (ar - e) + ai * ai > RX_TOL * RX_TOL) bad |= OFDMTX_RX_PILOTS;
                     }
                 }
-            } else if (code == -1) {
-                if (ar * ar + ai * ai > RX_TOL * RX_TOL) bad |= OFDMTX_RX_NULLS;
-            } else {
-                const float e = expected_pilot(P, T, lane, (k.pilot_base + s) % 127u);
-                if ((ar - e) * (ar - e) + ai * ai > RX_TOL * RX_TOL) bad |= OFDMTX_RX_PILOTS;
             }
             wave_sync();
         }
@@ -135,106 +250,146 @@ k_rx_demod(PlanParams P, DevTables T, const float2 *__restrict__ iq, uint8_t *__
     }
 }
 
-// MSB-first bit reader over the coded bytes of one packet
-struct BitReader {
+// The coded bits of one packet, MSB first, through a 64-bit window (next bit = bit 63)
+struct CodedWindow {
     const uint32_t *w;
-    uint32_t cur, left;
-    __device__ __forceinline__ explicit BitReader(const uint8_t *p) : w(reinterpret_cast<const uint32_t *>(p)), cur(0), left(0) {}
-    __device__ __forceinline__ uint32_t get()
+    uint32_t left;                 // words not yet fetched
+    uint64_t win;
+    uint32_t avail;
+    __device__ __forceinline__ void refill()
     {
-        if (left == 0) {
-            cur = __builtin_bswap32(*w++);
-            left = 32;
+        if (avail <= 32u && left) {
+            win |= (uint64_t)__builtin_bswap32(*w++) << (32u - avail);
+            avail += 32u;
+            left--;
         }
-        const uint32_t b = cur >> 31;
-        cur <<= 1;
-        left--;
-        return b;
     }
 };
 
-// One step of the decoder: hist bit d-1 = u[n-d].  g0 = 133 octal taps u[n] and the delays 2, 3, 5,
-// 6; g1 = 171 octal taps u[n] and the delays 1, 2, 3, 6 (17.3.5.5).  have: bit 0 = A received,
-// bit 1 = B received.  Returns u[n]; a redundant coded bit that contradicts it sets *mismatch.
-__device__ __forceinline__ uint32_t decode_step(uint32_t &hist, uint32_t have, uint32_t a, uint32_t b, uint32_t *mismatch)
+// Six steps of the decoder.  `hist` holds the decoded bits, newest in bit 0: bit d-1 = u[n-d].
+// g0 = 133 octal taps u[n] and the delays 2, 3, 5, 6; g1 = 171 octal taps u[n] and the delays 1, 2,
+// 3, 6 (17.3.5.5).  `pattern` says for each step which coded bits were sent (two bits per step, step
+// 0 lowest: bit 0 = A, bit 1 = B); u[n] follows from A where A was sent, from B otherwise, and where
+// both were sent the second one is checked against the first.  The six decoded bits are the low six
+// bits of hist afterwards.
+constexpr uint32_t PATTERN_1_2 = 0xFFFu;       // A B every step
+constexpr uint32_t PATTERN_3_4 = 0x9E7u;       // A0 B0 A1 B2 of every three steps (17.3.5.5, Figure 17-9)
+constexpr uint32_t PATTERN_2_3 = 0x777u;       // A0 B0 A1 of every two
+
+__device__ __forceinline__ void decode_six(CodedWindow &in, uint32_t &hist, uint32_t pattern, uint32_t &mismatch)
 {
-    const uint32_t pa = __popc(hist & 0x36u) & 1u, pb = __popc(hist & 0x27u) & 1u;
-    uint32_t u;
-    if (have & 1u) {
-        u = a ^ pa;
-        if ((have & 2u) && (b ^ pb) != u) *mismatch = 1u;
-    } else {
-        u = b ^ pb;
+    in.refill();                                            // at most 12 bits go
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const uint32_t have = (pattern >> (2 * i)) & 3u;
+        const uint32_t both = have == 3u ? 1u : 0u;
+        const uint32_t top = (uint32_t)(in.win >> 62);
+        const uint32_t first = top >> 1, second = both ? top : first;
+        const uint32_t ua = (first ^ __popc(hist & 0x36u)) & 1u;
+        const uint32_t ub = (second ^ __popc(hist & 0x27u)) & 1u;
+        mismatch |= both & (ua ^ ub);
+        hist = (hist << 1) | ((have & 1u) ? ua : ub);
+        in.win <<= 1u + both;
+        in.avail -= 1u + both;
     }
-    hist = ((hist << 1) | u) & 0x3Fu;
-    return u;
 }
 
+// One thread per packet.  The decoded bits are handled 32 at a time: descrambled with one XOR, bit-reversed
+// (17.3.5.1 sends every byte LSB first, so the reversed word holds four bytes in order), the bytes fed to the
+// CRC by table and stored as whole words where the payload buffer is aligned.
 template <bool UNIFORM>
 __global__ void __launch_bounds__(64)
 k_rx_decode(PlanParams P, DevTables T, const uint8_t *__restrict__ coded, uint8_t *__restrict__ payload_out,
             uint32_t *__restrict__ status)
 {
+    __shared__ uint32_t s_crc[256];                       // reflected CRC-32 of one byte (polynomial 0xEDB88320)
+    __shared__ uint32_t s_scr[127];                       // 32 bits of the scrambler's sequence from every phase
+    for (uint32_t i = threadIdx.x; i < 256u; i += 64u) {
+        uint32_t c = i;
+        for (int b = 0; b < 8; b++) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
+        s_crc[i] = c;
+    }
+    for (uint32_t i = threadIdx.x; i < 127u; i += 64u) s_scr[i] = T.scr_word[i];
+    __syncthreads();
+
     const uint32_t p = blockIdx.x * 64u + threadIdx.x;
     if (p >= P.n_pkts) return;
     const Pkt k = load_pkt<UNIFORM>(P, p);
     const RegimeInfo ri = regime_info((int)k.regime);
-    BitReader in(coded + k.msg_off);
+    const uint32_t msg_len = 6u + k.n_sym * (uint32_t)ri.n_cbps / 8u;
+    CodedWindow in = {reinterpret_cast<const uint32_t *>(coded + k.msg_off), (msg_len + 3u) / 4u, 0, 0u};
     uint32_t hist = 0, bad = 0, mism = 0;
 
     // ---- SIGNAL: 24 bits at rate 1/2 (17.3.4): RATE R1-R4, reserved, LENGTH (LSB first), parity, tail
-    uint32_t sig = 0;                                     // bit 23 - n = SIGNAL bit n
-    for (int n = 0; n < 24; n++) {
-        const uint32_t a = in.get(), b = in.get();
-        sig = (sig << 1) | decode_step(hist, 3u, a, b, &mism);
-    }
+    for (int i = 0; i < 4; i++) decode_six(in, hist, PATTERN_1_2, mism);
+    const uint32_t sig = hist & 0xFFFFFFu;                // bit 23 - n = SIGNAL bit n
     const uint32_t rate = sig >> 20;
-    uint32_t length = 0;
-    for (int i = 0; i < 12; i++) length |= ((sig >> (18 - i)) & 1u) << i;
+    const uint32_t length = (__brev(sig << 8) >> 5) & 0xFFFu;         // SIGNAL bits 5..16, LSB first
     if (rate != (uint32_t)ri.rate_bits || ((sig >> 19) & 1u) || (__popc(sig >> 6) & 1u) || (sig & 0x3Fu)) bad |= OFDMTX_RX_SIGNAL;
     // MAC header + payload + FCS (pu:28-36,193); a raw-PSDU plan's bytes are the whole PSDU, which
     // comes back whole (FCS included; without one -- fewer than four bytes -- nothing is checked)
     const bool raw = (P.flags & OFDMTX_F_RAW_PSDU) != 0;
-    const uint32_t hdr = raw ? 0u : 24u;
+    const int hdr = raw ? 0 : 24;
     const uint32_t want_len = raw ? k.pay_len : 24u + k.pay_len + 4u;
     const uint32_t fcs_at = want_len >= 4u ? want_len - 4u : want_len;   // first FCS byte
     if (length != want_len) bad |= OFDMTX_RX_LENGTH;
 
-    // ---- DATA: SERVICE (16 bits), PSDU, six tail bits, pad (17.3.5)
-    const uint32_t n_data = k.n_sym * (uint32_t)ri.n_dbps;
-    const uint32_t psdu_end = 16u + 8u * want_len;
-    uint32_t crc = 0xFFFFFFFFu, fcs = 0, byte = 0, phase = 0;
+    // ---- DATA: SERVICE (16 bits), PSDU, six tail bits, pad (17.3.5); N_dbps is a multiple of six
+    const uint32_t groups = k.n_sym * (uint32_t)ri.n_dbps / 6u;
+    const uint32_t pattern = ri.punct == 0 ? PATTERN_1_2 : ri.punct == 1 ? PATTERN_3_4 : PATTERN_2_3;
     uint8_t *pay = payload_out + k.pay_off;
-    for (uint32_t n = 0; n < n_data; n++) {
-        // 17.3.5.5, Figure 17-9: rate 3/4 sends A0 B0 A1 B2 of every three steps, rate 2/3 sends
-        // A0 B0 A1 of every two
-        uint32_t have = 3u;
-        if (ri.punct == 1) have = phase == 0 ? 3u : phase == 1 ? 1u : 2u;
-        if (ri.punct == 2) have = phase == 0 ? 3u : 1u;
-        phase++;
-        if ((ri.punct == 1 && phase == 3) || (ri.punct == 2 && phase == 2) || ri.punct == 0) phase = 0;
-        const uint32_t a = (have & 1u) ? in.get() : 0u, b = (have & 2u) ? in.get() : 0u;
-        const uint32_t scr = decode_step(hist, have, a, b, &mism);
+    const bool aligned = (reinterpret_cast<uintptr_t>(pay) & 3u) == 0;
+    const int n_store = (int)k.pay_len;
+    uint32_t crc = 0xFFFFFFFFu, fcs = 0, carry = 0, widx = 0, cnt = 0;
+    uint64_t acc = 0;
+
+    // payload bytes at[0..3] of `value`, as far as they exist
+    auto store4 = [&](int at, uint32_t value) {
+        if (at >= 0 && at + 4 <= n_store && aligned) {
+            *reinterpret_cast<uint32_t *>(pay + at) = value;
+        } else {
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+                if (at + b >= 0 && at + b < n_store) pay[at + b] = (uint8_t)(value >> (8 * b));
+        }
+    };
+    // decoded bits 32 widx .. 32 widx + 31, first one in bit 31: bytes 4 widx - 2 .. 4 widx + 1 of the PSDU
+    auto word = [&](uint32_t u) {
         // 17.3.5.4: the scrambler's 127-bit sequence, restarted with every packet (pu:344-358)
-        const uint32_t bit = scr ^ (T.scr_word[n % 127u] >> 31);
-        if (n < 16u) {
-            if (bit) bad |= OFDMTX_RX_SERVICE;
-        } else if (n < psdu_end) {
-            const uint32_t q = n - 16u, bi = q & 7u, by = q >> 3;
-            byte |= bit << bi;                            // 17.3.5.1: LSB first
-            if (by < fcs_at) {
-                crc = (crc >> 1) ^ (0xEDB88320u & (0u - ((crc ^ bit) & 1u)));
-            } else {
-                fcs |= bit << (q - 8u * fcs_at);
+        const uint32_t r = __brev(u ^ s_scr[(32u * widx) % 127u]);
+        const int by0 = 4 * (int)widx - 2;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int by = by0 + b;
+            const uint32_t byte = (r >> (8 * b)) & 0xFFu;
+            if (by < 0) {
+                if (byte) bad |= OFDMTX_RX_SERVICE;
+            } else if ((uint32_t)by < fcs_at) {
+                crc = s_crc[(crc ^ byte) & 0xFFu] ^ (crc >> 8);
+            } else if ((uint32_t)by < want_len) {
+                fcs |= byte << (8u * ((uint32_t)by - fcs_at));
+            } else if ((uint32_t)by == want_len) {
+                // the six tail bits are zero AFTER scrambling (17.3.5.2): looked at before the XOR
+                if ((u >> (24 - 8 * b)) & 0xFCu) bad |= OFDMTX_RX_TAIL;
             }
-            if (bi == 7u) {
-                if (by >= hdr && (raw || by < fcs_at)) pay[by - hdr] = (uint8_t)byte;
-                byte = 0;
-            }
-        } else if (n < psdu_end + 6u) {
-            if (scr) bad |= OFDMTX_RX_TAIL;               // tail bits are zero AFTER scrambling (17.3.5.2)
+        }
+        // payload bytes 4 widx - 4 - hdr .. : the second half of the word before, the first half of this one
+        store4(4 * (int)widx - 4 - hdr, carry | (r << 16));
+        carry = r >> 16;
+        widx++;
+    };
+
+    for (uint32_t g = 0; g < groups; g++) {
+        decode_six(in, hist, pattern, mism);
+        acc = (acc << 6) | (hist & 63u);
+        cnt += 6u;
+        if (cnt >= 32u) {
+            cnt -= 32u;
+            word((uint32_t)(acc >> cnt));
         }
     }
+    if (cnt) word((uint32_t)((acc & ((1ull << cnt) - 1ull)) << (32u - cnt)));
+    store4(4 * (int)widx - 4 - hdr, carry);
     if (fcs_at != want_len && (crc ^ 0xFFFFFFFFu) != fcs) bad |= OFDMTX_RX_FCS;
     if (mism) bad |= OFDMTX_RX_CODE;
     status[p] |= bad;
@@ -254,9 +409,16 @@ int ofdmtx_rx_demod(ofdmtx_ctx *ctx, const ofdmtx_plan *pl, const float *d_iq, u
     HIPCHK(hipSetDevice(ctx->device));
     const uint32_t wave_words = pl->tx_m_words + 4u;
     const size_t lds = (size_t)RX_WAVES * wave_words * sizeof(uint32_t);
-    if (lds > 60000) return OFDMTX_ETOOBIG;
+    if (lds > 44000) return OFDMTX_ETOOBIG;                       // next to the kernel's 20 KB of static LDS: under 64 KB
+    // one round of resident workgroups, each looping over packets: a second, partly filled round would
+    // run at a fraction of the occupancy
+    int per_cu = 0;
+    if (pl->pp.uniform)
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_rx_demod<true>, 64 * RX_WAVES, lds));
+    else
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_rx_demod<false>, 64 * RX_WAVES, lds));
     uint64_t blocks = ((uint64_t)pl->pp.n_pkts + RX_WAVES - 1) / RX_WAVES;
-    const uint64_t cap = (uint64_t)ctx->n_cu * 8u;
+    const uint64_t cap = (uint64_t)ctx->n_cu * (uint64_t)(per_cu > 0 ? per_cu : 1);
     if (blocks > cap) blocks = cap;
     const DevTables tab = ctx->tables();
     const float2 *iq = reinterpret_cast<const float2 *>(d_iq);

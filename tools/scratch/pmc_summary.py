@@ -13,5 +13,5 @@ for d in sys.argv[1:]:
         for row in csv.DictReader(open(f)):
             name = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
             acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
-out = {k: {c: sum(v) / len(v) for c, v in sorted(cs.items())} for k, cs in acc.items() if "k_raw" in k or "k_tx" in k or "k_enc" in k}
+out = {k: {c: sum(v) / len(v) for c, v in sorted(cs.items())} for k, cs in acc.items() if any(t in k for t in ("k_raw", "k_tx", "k_enc", "k_rx"))}
 print(json.dumps(out, indent=1))
