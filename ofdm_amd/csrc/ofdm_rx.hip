@@ -250,18 +250,20 @@ k_rx_demod(PlanParams P, DevTables T, const float2 *__restrict__ iq, uint8_t *__
     }
 }
 
-// The coded bits of one packet, MSB first, through a 64-bit window (next bit = bit 63)
+// The coded bits of one packet, MSB first, through a 64-bit window (next bit = bit 63).  The words come
+// from the packet's row of the LDS staging area, which holds words first .. end - 1 of the packet.
 struct CodedWindow {
-    const uint32_t *w;
-    uint32_t left;                 // words not yet fetched
+    const uint32_t *row;           // word `first` of the packet
+    uint32_t first, end;           // staged at present
+    uint32_t pos;                  // next word to take
     uint64_t win;
     uint32_t avail;
     __device__ __forceinline__ void refill()
     {
-        if (avail <= 32u && left) {
-            win |= (uint64_t)__builtin_bswap32(*w++) << (32u - avail);
+        if (avail <= 32u && pos < end) {
+            win |= (uint64_t)__builtin_bswap32(row[pos - first]) << (32u - avail);
             avail += 32u;
-            left--;
+            pos++;
         }
     }
 };
@@ -294,9 +296,46 @@ __device__ __forceinline__ void decode_six(CodedWindow &in, uint32_t &hist, uint
     }
 }
 
-// One thread per packet.  The decoded bits are handled 32 at a time: descrambled with one XOR, bit-reversed
-// (17.3.5.1 sends every byte LSB first, so the reversed word holds four bytes in order), the bytes fed to the
-// CRC by table and stored as whole words where the payload buffer is aligned.
+// The same with the pattern known to the compiler (every packet of a uniform plan has it): the group's coded
+// bits are taken from fixed positions of the window's upper half, the window moves once.  Only bit 0 of
+// `mismatch` means anything.
+template <uint32_t PATTERN>
+__device__ __forceinline__ void decode_six_fixed(CodedWindow &in, uint32_t &hist, uint32_t &mismatch)
+{
+    in.refill();
+    const uint32_t bits = (uint32_t)(in.win >> 32);        // the next 32 coded bits, first one in bit 31
+    int at = 31;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const uint32_t have = (PATTERN >> (2 * i)) & 3u;
+        uint32_t u;
+        if (have == 3u) {
+            u = __popc(hist & 0x36u) + (bits >> at);
+            mismatch |= u ^ (__popc(hist & 0x27u) + (bits >> (at - 1)));
+            at -= 2;
+        } else {
+            u = __popc(hist & (have == 1u ? 0x36u : 0x27u)) + (bits >> at);
+            at -= 1;
+        }
+        hist = (hist << 1) | (u & 1u);
+    }
+    in.win <<= 31 - at;
+    in.avail -= (uint32_t)(31 - at);
+}
+
+constexpr int DEC_CHUNK = 16;          // coded words of every packet staged per round
+constexpr int DEC_PER = 64 / DEC_CHUNK;  // packets a wave-wide load or store covers
+constexpr int DEC_TURNS = 64 / DEC_PER;
+constexpr int DEC_ROW = DEC_CHUNK + 1; // row pitch of the staging areas, in words (odd: lanes walk their own rows)
+
+// One wavefront per 64 packets, one lane per packet.  A packet's coded bytes and its payload bytes lie apart
+// from the next packet's, so lanes reading and writing their own packets word by word would touch 64
+// memory lines per instruction.  Instead the wave works in rounds: the next DEC_CHUNK coded words of every
+// packet are fetched by the whole wave (DEC_CHUNK lanes per packet, contiguous bytes) into LDS, every lane
+// decodes what was staged for its packet and leaves the payload words in LDS, the wave stores them
+// (DEC_CHUNK lanes per packet again; a round leaves fewer payload words than it takes coded ones).  The decoded bits are handled 32 at a time: descrambled with one XOR,
+// bit-reversed (17.3.5.1 sends every byte LSB first, so the reversed word holds four bytes in order), the
+// bytes fed to the CRC by table.
 template <bool UNIFORM>
 __global__ void __launch_bounds__(64)
 k_rx_decode(PlanParams P, DevTables T, const uint8_t *__restrict__ coded, uint8_t *__restrict__ payload_out,
@@ -304,54 +343,56 @@ k_rx_decode(PlanParams P, DevTables T, const uint8_t *__restrict__ coded, uint8_
 {
     __shared__ uint32_t s_crc[256];                       // reflected CRC-32 of one byte (polynomial 0xEDB88320)
     __shared__ uint32_t s_scr[127];                       // 32 bits of the scrambler's sequence from every phase
-    for (uint32_t i = threadIdx.x; i < 256u; i += 64u) {
+    __shared__ uint32_t s_in[64 * DEC_ROW], s_out[64 * DEC_ROW];
+    __shared__ uint64_t s_src[64], s_dst[64];             // per packet: coded words, payload bytes
+    __shared__ uint32_t s_words[64], s_count[64];         // coded words of the packet; payload words left this round
+    __shared__ int s_store[64], s_at[64];                 // payload bytes of the packet; position of the first word left
+
+    const int lane = threadIdx.x, part = lane / DEC_CHUNK, col = lane % DEC_CHUNK;
+    for (uint32_t i = lane; i < 256u; i += 64u) {
         uint32_t c = i;
         for (int b = 0; b < 8; b++) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
         s_crc[i] = c;
     }
-    for (uint32_t i = threadIdx.x; i < 127u; i += 64u) s_scr[i] = T.scr_word[i];
-    __syncthreads();
+    for (uint32_t i = lane; i < 127u; i += 64u) s_scr[i] = T.scr_word[i];
 
-    const uint32_t p = blockIdx.x * 64u + threadIdx.x;
-    if (p >= P.n_pkts) return;
-    const Pkt k = load_pkt<UNIFORM>(P, p);
+    const uint32_t p = blockIdx.x * 64u + (uint32_t)lane;
+    const bool valid = p < P.n_pkts;                      // a lane without a packet helps with the copies
+    const Pkt k = load_pkt<UNIFORM>(P, valid ? p : 0u);
     const RegimeInfo ri = regime_info((int)k.regime);
-    const uint32_t msg_len = 6u + k.n_sym * (uint32_t)ri.n_cbps / 8u;
-    CodedWindow in = {reinterpret_cast<const uint32_t *>(coded + k.msg_off), (msg_len + 3u) / 4u, 0, 0u};
-    uint32_t hist = 0, bad = 0, mism = 0;
-
-    // ---- SIGNAL: 24 bits at rate 1/2 (17.3.4): RATE R1-R4, reserved, LENGTH (LSB first), parity, tail
-    for (int i = 0; i < 4; i++) decode_six(in, hist, PATTERN_1_2, mism);
-    const uint32_t sig = hist & 0xFFFFFFu;                // bit 23 - n = SIGNAL bit n
-    const uint32_t rate = sig >> 20;
-    const uint32_t length = (__brev(sig << 8) >> 5) & 0xFFFu;         // SIGNAL bits 5..16, LSB first
-    if (rate != (uint32_t)ri.rate_bits || ((sig >> 19) & 1u) || (__popc(sig >> 6) & 1u) || (sig & 0x3Fu)) bad |= OFDMTX_RX_SIGNAL;
+    const uint32_t n_words = valid ? (6u + k.n_sym * (uint32_t)ri.n_cbps / 8u + 3u) / 4u : 0u;
     // MAC header + payload + FCS (pu:28-36,193); a raw-PSDU plan's bytes are the whole PSDU, which
     // comes back whole (FCS included; without one -- fewer than four bytes -- nothing is checked)
     const bool raw = (P.flags & OFDMTX_F_RAW_PSDU) != 0;
     const int hdr = raw ? 0 : 24;
     const uint32_t want_len = raw ? k.pay_len : 24u + k.pay_len + 4u;
     const uint32_t fcs_at = want_len >= 4u ? want_len - 4u : want_len;   // first FCS byte
-    if (length != want_len) bad |= OFDMTX_RX_LENGTH;
-
-    // ---- DATA: SERVICE (16 bits), PSDU, six tail bits, pad (17.3.5); N_dbps is a multiple of six
-    const uint32_t groups = k.n_sym * (uint32_t)ri.n_dbps / 6u;
+    const int n_store = valid ? (int)k.pay_len : 0;
+    // DATA: SERVICE (16 bits), PSDU, six tail bits, pad (17.3.5); N_dbps is a multiple of six
+    const uint32_t groups = valid ? k.n_sym * (uint32_t)ri.n_dbps / 6u : 0u;
     const uint32_t pattern = ri.punct == 0 ? PATTERN_1_2 : ri.punct == 1 ? PATTERN_3_4 : PATTERN_2_3;
-    uint8_t *pay = payload_out + k.pay_off;
-    const bool aligned = (reinterpret_cast<uintptr_t>(pay) & 3u) == 0;
-    const int n_store = (int)k.pay_len;
-    uint32_t crc = 0xFFFFFFFFu, fcs = 0, carry = 0, widx = 0, cnt = 0;
+    s_src[lane] = reinterpret_cast<uint64_t>(coded + k.msg_off);
+    s_dst[lane] = reinterpret_cast<uint64_t>(payload_out + k.pay_off);
+    s_words[lane] = n_words;
+    s_store[lane] = n_store;
+    uint32_t most = n_words;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) most = max(most, (uint32_t)__shfl_xor((int)most, o));
+    __syncthreads();
+
+    CodedWindow in = {s_in + lane * DEC_ROW, 0u, 0u, 0u, 0, 0u};
+    uint32_t hist = 0, bad = 0, mism = 0;
+    uint32_t crc = 0xFFFFFFFFu, fcs = 0, carry = 0, widx = 0, cnt = 0, g = 0, n_left = 0;
+    int at_left = 0;
+    bool finished = !valid;
     uint64_t acc = 0;
 
-    // payload bytes at[0..3] of `value`, as far as they exist
-    auto store4 = [&](int at, uint32_t value) {
-        if (at >= 0 && at + 4 <= n_store && aligned) {
-            *reinterpret_cast<uint32_t *>(pay + at) = value;
-        } else {
-#pragma unroll
-            for (int b = 0; b < 4; b++)
-                if (at + b >= 0 && at + b < n_store) pay[at + b] = (uint8_t)(value >> (8 * b));
-        }
+    // four payload bytes for position `at` of the packet: kept for the wave to store, unless none of them exists
+    auto leave = [&](int at, uint32_t value) {
+        if (at + 4 <= 0 || at >= n_store) return;
+        if (n_left == 0u) at_left = at;
+        s_out[lane * DEC_ROW + (int)n_left] = value;
+        n_left++;
     };
     // decoded bits 32 widx .. 32 widx + 31, first one in bit 31: bytes 4 widx - 2 .. 4 widx + 1 of the PSDU
     auto word = [&](uint32_t u) {
@@ -374,25 +415,94 @@ k_rx_decode(PlanParams P, DevTables T, const uint8_t *__restrict__ coded, uint8_
             }
         }
         // payload bytes 4 widx - 4 - hdr .. : the second half of the word before, the first half of this one
-        store4(4 * (int)widx - 4 - hdr, carry | (r << 16));
+        leave(4 * (int)widx - 4 - hdr, carry | (r << 16));
         carry = r >> 16;
         widx++;
     };
-
-    for (uint32_t g = 0; g < groups; g++) {
-        decode_six(in, hist, pattern, mism);
+    auto six_done = [&]() {
         acc = (acc << 6) | (hist & 63u);
         cnt += 6u;
         if (cnt >= 32u) {
             cnt -= 32u;
             word((uint32_t)(acc >> cnt));
         }
+        g++;
+    };
+    // a group takes at most 12 coded bits: they are in the window, or the next word is staged, or there is
+    // no next word (a packet's words hold all the bits its groups take)
+    auto can_go = [&]() { return g < groups && (in.avail >= 12u || in.pos < in.end || in.pos >= n_words); };
+
+    // words c0 .. c0 + DEC_CHUNK - 1 of every packet, DEC_PER packets per load: fetched one round ahead and
+    // held in registers while the round before is decoded
+    uint32_t ahead[DEC_TURNS] = {};
+    auto fetch = [&](uint32_t c0) {
+#pragma unroll
+        for (int i = 0; i < DEC_TURNS; i++) {
+            const int pk = DEC_PER * i + part;
+            if (c0 + (uint32_t)col < s_words[pk]) ahead[i] = reinterpret_cast<const uint32_t *>(s_src[pk])[c0 + (uint32_t)col];
+        }
+    };
+    fetch(0u);
+    for (uint32_t c0 = 0; c0 < most; c0 += DEC_CHUNK) {
+#pragma unroll
+        for (int i = 0; i < DEC_TURNS; i++) s_in[(DEC_PER * i + part) * DEC_ROW + col] = ahead[i];
+        wave_sync();
+        if (c0 + DEC_CHUNK < most) fetch(c0 + DEC_CHUNK);
+        in.first = c0;
+        in.end = min(n_words, c0 + (uint32_t)DEC_CHUNK);
+        n_left = 0;
+        if (c0 == 0u && valid) {
+            // ---- SIGNAL: 24 bits at rate 1/2 (17.3.4): RATE R1-R4, reserved, LENGTH (LSB first), parity, tail
+            for (int i = 0; i < 4; i++) decode_six(in, hist, PATTERN_1_2, mism);
+            const uint32_t sig = hist & 0xFFFFFFu;            // bit 23 - n = SIGNAL bit n
+            const uint32_t rate = sig >> 20;
+            const uint32_t length = (__brev(sig << 8) >> 5) & 0xFFFu;     // SIGNAL bits 5..16, LSB first
+            if (rate != (uint32_t)ri.rate_bits || ((sig >> 19) & 1u) || (__popc(sig >> 6) & 1u) || (sig & 0x3Fu)) bad |= OFDMTX_RX_SIGNAL;
+            if (length != want_len) bad |= OFDMTX_RX_LENGTH;
+        }
+        if (UNIFORM && ri.punct == 0) {
+            while (can_go()) { decode_six_fixed<PATTERN_1_2>(in, hist, mism); six_done(); }
+        } else if (UNIFORM && ri.punct == 1) {
+            while (can_go()) { decode_six_fixed<PATTERN_3_4>(in, hist, mism); six_done(); }
+        } else if (UNIFORM) {
+            while (can_go()) { decode_six_fixed<PATTERN_2_3>(in, hist, mism); six_done(); }
+        } else {
+            // packets of a ragged plan differ from lane to lane
+            while (can_go()) { decode_six(in, hist, pattern, mism); six_done(); }
+        }
+        if (g == groups && !finished) {
+            if (cnt) word((uint32_t)((acc & ((1ull << cnt) - 1ull)) << (32u - cnt)));
+            leave(4 * (int)widx - 4 - hdr, carry);
+            finished = true;
+        }
+        s_count[lane] = n_left;
+        s_at[lane] = at_left;
+        wave_sync();
+        // ---- the payload words left in LDS out to memory: whole words where the packet's bytes are
+        // aligned and the word lies inside the payload, single bytes otherwise
+#pragma unroll 4
+        for (int i = 0; i < DEC_TURNS; i++) {
+            const int pk = DEC_PER * i + part;
+            if ((uint32_t)col < s_count[pk]) {
+                uint8_t *pay = reinterpret_cast<uint8_t *>(s_dst[pk]);
+                const int at = s_at[pk] + 4 * col, len = s_store[pk];
+                const uint32_t value = s_out[pk * DEC_ROW + col];
+                if (at >= 0 && at + 4 <= len && (s_dst[pk] & 3u) == 0) {
+                    *reinterpret_cast<uint32_t *>(pay + at) = value;
+                } else {
+#pragma unroll
+                    for (int b = 0; b < 4; b++)
+                        if (at + b >= 0 && at + b < len) pay[at + b] = (uint8_t)(value >> (8 * b));
+                }
+            }
+        }
+        wave_sync();
     }
-    if (cnt) word((uint32_t)((acc & ((1ull << cnt) - 1ull)) << (32u - cnt)));
-    store4(4 * (int)widx - 4 - hdr, carry);
-    if (fcs_at != want_len && (crc ^ 0xFFFFFFFFu) != fcs) bad |= OFDMTX_RX_FCS;
-    if (mism) bad |= OFDMTX_RX_CODE;
-    status[p] |= bad;
+    if (valid) {
+        if (fcs_at != want_len && (crc ^ 0xFFFFFFFFu) != fcs) bad |= OFDMTX_RX_FCS;
+        if (mism & 1u) bad |= OFDMTX_RX_CODE;
+        status[p] |= bad;
+    }
 }
 
 }  // namespace
