@@ -8,6 +8,7 @@ import pytest
 import torch
 
 from ofdm_amd import _lib
+from oracle import ftw_oracle as o
 
 pytestmark = pytest.mark.gpu
 
@@ -118,6 +119,35 @@ def test_custom_constellation_loops_back(txctx):
         rng = np.random.default_rng(62)
         pay = torch.from_numpy(rng.integers(0, 256, 4 * 90, dtype=np.uint8)).to(ctx.device)
         plan = ctx.plan_uniform(4, 4, 90)
+        got, status = plan.loopback(plan.tx(pay))
+        assert int(status.abs().max()) == 0 and torch.equal(got, pay)
+        plan.close()
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("kind", ["rotated", "product"])
+@pytest.mark.parametrize("nbits,regime", [(4, 6), (6, 8)])
+def test_custom_qam_tables_loop_back(kind, nbits, regime):
+    """16-QAM / 64-QAM tables of the caller's own: one whose points are NOT (I[first half of the bits],
+    Q[second half]) -- the standard table turned by 30 degrees, searched point by point -- and one that is such
+    a product with unevenly spaced levels in no particular order (searched axis by axis)."""
+    from ofdm_amd.batch import TxContext
+    ctx = TxContext(0)
+    try:
+        h = nbits // 2
+        if kind == "rotated":
+            std = o.tables().constellation["qam16" if nbits == 4 else "qam64"].astype(np.complex64)
+            pts = (std * np.exp(1j * np.pi / 6)).astype(np.complex64)
+        else:
+            lv = np.random.default_rng(7).permutation(np.cumsum(np.linspace(0.11, 0.23, 1 << h)) - 0.6).astype(np.float32)
+            idx = np.arange(1 << nbits)
+            pts = (lv[idx >> h] + 1j * lv[::-1][idx & ((1 << h) - 1)]).astype(np.complex64)
+        ctx.set_constellation(nbits, pts)
+        rng = np.random.default_rng(63)
+        lens = rng.integers(1, 700, 37).astype(np.uint32)
+        pay = torch.from_numpy(rng.integers(0, 256, int(lens.sum()), dtype=np.uint8)).to(ctx.device)
+        plan = ctx.plan_ragged(np.full(37, regime, np.uint8), lens)
         got, status = plan.loopback(plan.tx(pay))
         assert int(status.abs().max()) == 0 and torch.equal(got, pay)
         plan.close()
