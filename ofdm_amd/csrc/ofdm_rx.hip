@@ -64,12 +64,21 @@ __device__ __forceinline__ void deinterleave_carrier(uint32_t *W, uint32_t hw0, 
         v = ((((hi >> rot) | (hi << (SG - rot))) & MASK) << SG) | (((lo >> rot) | (lo << (SG - rot))) & MASK);
     }
     const uint32_t first = hw0 + (code - 3u * c) * NB;
+    if constexpr (NB == 1) {
+        if (v) atomicOr(&W[first >> 1], 1u << (((~first & 1u) << 4) + 15u - c));
+    } else {
+        // A symbol starts at an odd unit (three units of SIGNAL, then an even number per symbol) and so does
+        // every carrier's run: bit 0 is the low half of a word, bits 1 and 2 are the next word, ..., the
+        // last bit is a high half.  No branches: a word that gets no one is ORed with zero.
+        uint32_t *w = W + (first >> 1);
+        const uint32_t sh = 15u - c;
+        atomicOr(w, (v >> (NB - 1)) << sh);
 #pragma unroll
-    for (int t = 0; t < NB; t++) {
-        if ((v >> (NB - 1 - t)) & 1u) {
-            const uint32_t hw = first + (uint32_t)t;
-            atomicOr(&W[hw >> 1], 1u << (((~hw & 1u) << 4) + 15u - c));
+        for (int k = 1; k < NB / 2; k++) {
+            const uint32_t x = (v >> (NB - 1 - 2 * k)) & 3u;                   // bits 2k - 1 (upper half) and 2k
+            atomicOr(w + k, ((x | (x << 15)) & 0x10001u) << sh);
         }
+        atomicOr(w + NB / 2, (v & 1u) << (16u + sh));
     }
 }
 
