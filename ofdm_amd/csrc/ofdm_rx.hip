@@ -52,18 +52,28 @@ __device__ __forceinline__ float expected_pilot(const PlanParams &P, const DevTa
 // rotated right by c mod s, and bit t of the result is coded bit 16 (d NB + t) + c of the symbol --
 // bit c of the 16-bit unit number d NB + t.  `hw0` = 16-bit units of the packet before this symbol;
 // the ones are ORed into the packet's MSB-first words.
+// What a lane has to know about one of its FFT bins, packed: bits 0..7 the bin's code (bin_code, signed),
+// and for a data carrier 3 c + d: bits 8..11 c, 12..13 d, 14 c mod 2, 15..16 c mod 3.
+__host__ __device__ constexpr uint32_t bin_info(int bin)
+{
+    const int code = bin_code(bin);
+    if (code < 0) return (uint32_t)code & 0xFFu;
+    const uint32_t c = (uint32_t)code / 3u, d = (uint32_t)code % 3u;
+    return (uint32_t)code | (c << 8) | (d << 12) | ((c % 2u) << 14) | ((c % 3u) << 15);
+}
+
 template <int NB>
-__device__ __forceinline__ void deinterleave_carrier(uint32_t *W, uint32_t hw0, uint32_t code, uint32_t best)
+__device__ __forceinline__ void deinterleave_carrier(uint32_t *W, uint32_t hw0, uint32_t info, uint32_t best)
 {
     constexpr uint32_t SG = NB / 2 > 1 ? NB / 2 : 1, MASK = (1u << SG) - 1u;
-    const uint32_t c = (code * 43u) >> 7;                                  // code / 3, code < 48
+    const uint32_t c = (info >> 8) & 15u;
     uint32_t v = best;
     if (SG > 1) {
-        const uint32_t rot = SG == 2 ? (c & 1u) : c - 3u * ((c * 11u) >> 5);           // c mod s, c < 16
+        const uint32_t rot = SG == 2 ? (info >> 14) & 1u : (info >> 15) & 3u;           // c mod s
         const uint32_t hi = v >> SG, lo = v & MASK;
         v = ((((hi >> rot) | (hi << (SG - rot))) & MASK) << SG) | (((lo >> rot) | (lo << (SG - rot))) & MASK);
     }
-    const uint32_t first = hw0 + (code - 3u * c) * NB;
+    const uint32_t first = hw0 + ((info >> 12) & 3u) * NB;
     if constexpr (NB == 1) {
         if (v) atomicOr(&W[first >> 1], 1u << (((~first & 1u) << 4) + 15u - c));
     } else {
@@ -82,14 +92,62 @@ __device__ __forceinline__ void deinterleave_carrier(uint32_t *W, uint32_t hw0, 
     }
 }
 
-// index of the level nearest to x: the low three bits of each distance are replaced by the level's number, so
-// that one unsigned minimum finds both (distances are not negative: their bit patterns order as integers)
+// index of the level nearest to x among the first L: the low three bits of each distance are replaced by the
+// level's number, so that one unsigned minimum finds both (distances are not negative: their bit patterns order
+// as integers)
+template <int L>
 __device__ __forceinline__ uint32_t nearest_level(float x, const float (&lv)[8])
 {
     uint32_t m = 0xFFFFFFFFu;
 #pragma unroll
-    for (int a = 0; a < 8; a++) m = min(m, (__float_as_uint(fabsf(x - lv[a])) & ~7u) | (uint32_t)a);
+    for (int a = 0; a < L; a++) m = min(m, (__float_as_uint(fabsf(x - lv[a])) & ~7u) | (uint32_t)a);
     return m & 7u;
+}
+
+// The eight bins 8 q + l of one symbol whose data carriers hold NB bits: decisions against the table, the coded
+// bits into W, pilot and null-carrier checks.  x[q] = (im, re) of the bin.  The table: (ti[a], tq[b]) for
+// point (a << NB/2) | b where it is a product (per_axis); BPSK / QPSK: the points (ti[i], tq[i]); otherwise
+// the points in LDS.  Returns the status bits.
+template <int NB>
+__device__ __forceinline__ uint32_t decide_bins(const v2f (&x)[8], int l, const uint32_t *s_info, const float (&ti)[8],
+                                                const float (&tq)[8], bool per_axis, const float2 *points, uint32_t *W,
+                                                uint32_t hw0, const PlanParams &P, const DevTables &T, uint32_t pidx)
+{
+    uint32_t bad = 0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int bin = 8 * q + l;
+        const uint32_t info = s_info[bin];
+        const int code = (int)(int8_t)(info & 0xFFu);
+        const float ar = x[q].y, ai = x[q].x;
+        if (code >= 0) {
+            uint32_t best = 0;
+            if (NB >= 4 && per_axis) {
+                best = (nearest_level<(1 << (NB / 2))>(ar, ti) << (NB / 2)) | nearest_level<(1 << (NB / 2))>(ai, tq);
+            } else if (NB <= 2) {
+                float best_d = 3.0e38f;
+#pragma unroll
+                for (int i = 0; i < (1 << NB); i++) {
+                    const float d = (ar - ti[i]) * (ar - ti[i]) + (ai - tq[i]) * (ai - tq[i]);
+                    if (d < best_d) { best_d = d; best = (uint32_t)i; }
+                }
+            } else {
+                float best_d = 3.0e38f;
+                for (int i = 0; i < (1 << NB); i++) {
+                    const float2 c = points[i];
+                    const float d = (ar - c.x) * (ar - c.x) + (ai - c.y) * (ai - c.y);
+                    if (d < best_d) { best_d = d; best = (uint32_t)i; }
+                }
+            }
+            deinterleave_carrier<NB>(W, hw0, info, best);
+        } else if (code == -1) {
+            if (ar * ar + ai * ai > RX_TOL * RX_TOL) bad |= OFDMTX_RX_NULLS;
+        } else {
+            const float e = expected_pilot(P, T, bin, pidx);
+            if ((ar - e) * (ar - e) + ai * ai > RX_TOL * RX_TOL) bad |= OFDMTX_RX_PILOTS;
+        }
+    }
+    return bad;
 }
 
 constexpr int RX_TG = 72;              // float2 per symbol in the transposition layout (8 rows x 9)
@@ -108,7 +166,7 @@ k_rx_demod(PlanParams P, DevTables T, const float2 *__restrict__ iq, uint8_t *__
     __shared__ v2f s_tw[64];                              // W64^{l p} / (8 amp) at 8 p + l
     __shared__ float2 s_lut[LUT_SIZE];
     __shared__ v2f s_t[RX_WAVES][8 * RX_TG];
-    __shared__ int s_code[64];                            // what each FFT bin carries
+    __shared__ uint32_t s_info[64];                       // what each FFT bin carries (bin_info)
     __shared__ int s_sep[2];                              // the 16-QAM / 64-QAM table is a product I[hi] x Q[lo]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -119,7 +177,7 @@ k_rx_demod(PlanParams P, DevTables T, const float2 *__restrict__ iq, uint8_t *__
     for (int i = tid; i < 64; i += 64 * RX_WAVES) {
         const float2 w = T.tw64[((i & 7) * (i >> 3)) & 63];
         s_tw[i] = (v2f){w.x * inv, w.y * inv};
-        s_code[i] = bin_code(i);
+        s_info[i] = bin_info(i);
     }
     for (int i = tid; i < LUT_SIZE; i += 64 * RX_WAVES) s_lut[i] = T.lut[i];
     if (tid < 2) s_sep[tid] = 1;
@@ -136,10 +194,11 @@ k_rx_demod(PlanParams P, DevTables T, const float2 *__restrict__ iq, uint8_t *__
 
     uint32_t *W = s_rxw + (size_t)wave * wave_words;
     v2f *buf = s_t[wave];
-    float2 sig[2];                                        // the SIGNAL symbol's two points, in scalar registers
-    for (int i = 0; i < 2; i++)
-        sig[i] = make_float2(__uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_lut[LUT_PM1 + i].x))),
-                             __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_lut[LUT_PM1 + i].y))));
+    float sig_i[8] = {}, sig_q[8] = {};                   // the SIGNAL symbol's two points, in scalar registers
+    for (int i = 0; i < 2; i++) {
+        sig_i[i] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_lut[LUT_PM1 + i].x)));
+        sig_q[i] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_lut[LUT_PM1 + i].y)));
+    }
     const bool swap_iq = (P.flags & OFDMTX_F_SWAPIQ) != 0;
     const uint32_t pre_rows = (P.flags & OFDMTX_F_PREAMBLE)
                                   ? ((P.flags & (OFDMTX_F_PNC_A | OFDMTX_F_PNC_B)) ? 6u : 4u) : 0u;
@@ -201,49 +260,18 @@ k_rx_demod(PlanParams P, DevTables T, const float2 *__restrict__ iq, uint8_t *__
                 for (int i = 0; i < 8; i++) x[i] = buf[g * RX_TG + 9 * l + i];
                 idft8(x);                                 // x[q] = (im, re) of bin 8 q + l
 
-                // SIGNAL is BPSK whatever the rate (17.3.4)
-                const int nb = s == 0 ? 1 : ri.n_bpsc;
-                const int off = s == 0 ? LUT_PM1 : ri.lut_off;
-                const uint32_t hw0 = s == 0 ? 0u : 3u + (s - 1u) * (uint32_t)ri.n_cbps / 16u;
                 const uint32_t pidx = (k.pilot_base + s) % 127u;
-                const bool per_axis = by_axis && s != 0;
-#pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const int bin = 8 * q + l, code = s_code[bin];
-                    const float ar = x[q].y, ai = x[q].x;
-                    if (code >= 0) {
-                        // nearest constellation point
-                        uint32_t best = 0;
-                        if (per_axis) {
-                            best = (nearest_level(ar, lv_i) << h) | nearest_level(ai, lv_q);
-                        } else if (nb <= 2) {
-                            float best_d = 3.0e38f;
-#pragma unroll
-                            for (int i = 0; i < 4; i++) {
-                                const float2 c = s == 0 ? (i < 2 ? sig[i] : make_float2(1.0e18f, 1.0e18f))
-                                                        : make_float2(lv_i[i], lv_q[i]);
-                                const float d = (ar - c.x) * (ar - c.x) + (ai - c.y) * (ai - c.y);
-                                if (d < best_d) { best_d = d; best = (uint32_t)i; }
-                            }
-                        } else {
-                            float best_d = 3.0e38f;
-                            for (int i = 0; i < (1 << nb); i++) {
-                                const float2 c = s_lut[off + i];
-                                const float d = (ar - c.x) * (ar - c.x) + (ai - c.y) * (ai - c.y);
-                                if (d < best_d) { best_d = d; best = (uint32_t)i; }
-                            }
-                        }
-                        switch (nb) {
-                        case 1: deinterleave_carrier<1>(W, hw0, (uint32_t)code, best); break;
-                        case 2: deinterleave_carrier<2>(W, hw0, (uint32_t)code, best); break;
-                        case 4: deinterleave_carrier<4>(W, hw0, (uint32_t)code, best); break;
-                        default: deinterleave_carrier<6>(W, hw0, (uint32_t)code, best); break;
-                        }
-                    } else if (code == -1) {
-                        if (ar * ar + ai * ai > RX_TOL * RX_TOL) bad |= OFDMTX_RX_NULLS;
-                    } else {
-                        const float e = expected_pilot(P, T, bin, pidx);
-                        if ((ar - e) * (ar - e) + ai * ai > RX_TOL * RX_TOL) bad |= OFDMTX_RX_PILOTS;
+                if (s == 0) {
+                    // SIGNAL is BPSK whatever the rate (17.3.4)
+                    bad |= decide_bins<1>(x, l, s_info, sig_i, sig_q, false, s_lut, W, 0u, P, T, pidx);
+                } else {
+                    const uint32_t hw0 = 3u + (s - 1u) * (uint32_t)ri.n_cbps / 16u;
+                    const float2 *points = s_lut + ri.lut_off;
+                    switch (ri.n_bpsc) {
+                    case 1: bad |= decide_bins<1>(x, l, s_info, lv_i, lv_q, false, points, W, hw0, P, T, pidx); break;
+                    case 2: bad |= decide_bins<2>(x, l, s_info, lv_i, lv_q, false, points, W, hw0, P, T, pidx); break;
+                    case 4: bad |= decide_bins<4>(x, l, s_info, lv_i, lv_q, by_axis, points, W, hw0, P, T, pidx); break;
+                    default: bad |= decide_bins<6>(x, l, s_info, lv_i, lv_q, by_axis, points, W, hw0, P, T, pidx); break;
                     }
                 }
             }
