@@ -310,7 +310,7 @@ struct CodedWindow {
 // 3, 6 (17.3.5.5).  `pattern` says for each step which coded bits were sent (two bits per step, step
 // 0 lowest: bit 0 = A, bit 1 = B); u[n] follows from A where A was sent, from B otherwise, and where
 // both were sent the second one is checked against the first.  The six decoded bits are the low six
-// bits of hist afterwards.
+// bits of hist afterwards; only bit 0 of `mismatch` means anything.
 constexpr uint32_t PATTERN_1_2 = 0xFFFu;       // A B every step
 constexpr uint32_t PATTERN_3_4 = 0x9E7u;       // A0 B0 A1 B2 of every three steps (17.3.5.5, Figure 17-9)
 constexpr uint32_t PATTERN_2_3 = 0x777u;       // A0 B0 A1 of every two
@@ -318,24 +318,26 @@ constexpr uint32_t PATTERN_2_3 = 0x777u;       // A0 B0 A1 of every two
 __device__ __forceinline__ void decode_six(CodedWindow &in, uint32_t &hist, uint32_t pattern, uint32_t &mismatch)
 {
     in.refill();                                            // at most 12 bits go
+    const uint32_t bits = (uint32_t)(in.win >> 32);        // the next 32 coded bits, first one in bit 31
+    const uint32_t both_of = pattern & (pattern >> 1);     // bit 2 i: both coded bits of step i were sent
+    uint32_t at = 31u;
 #pragma unroll
     for (int i = 0; i < 6; i++) {
-        const uint32_t have = (pattern >> (2 * i)) & 3u;
-        const uint32_t both = have == 3u ? 1u : 0u;
-        const uint32_t top = (uint32_t)(in.win >> 62);
-        const uint32_t first = top >> 1, second = both ? top : first;
-        const uint32_t ua = (first ^ __popc(hist & 0x36u)) & 1u;
-        const uint32_t ub = (second ^ __popc(hist & 0x27u)) & 1u;
-        mismatch |= both & (ua ^ ub);
-        hist = (hist << 1) | ((have & 1u) ? ua : ub);
-        in.win <<= 1u + both;
-        in.avail -= 1u + both;
+        const uint32_t both = (both_of >> (2 * i)) & 1u;
+        // what the step's first bit says if it is A, what its last bit says if it is B (bit 0 of each)
+        const uint32_t ua = __popc(hist & 0x36u) + (bits >> at);
+        const uint32_t ub = __popc(hist & 0x27u) + (bits >> (at - both));
+        const uint32_t differ = ua ^ ub;
+        mismatch |= differ & both;
+        hist = (hist << 1) | ((ub ^ (differ & (pattern >> (2 * i)))) & 1u);      // A's word where A was sent
+        at -= 1u + both;
     }
+    in.win <<= 31u - at;
+    in.avail -= 31u - at;
 }
 
 // The same with the pattern known to the compiler (every packet of a uniform plan has it): the group's coded
-// bits are taken from fixed positions of the window's upper half, the window moves once.  Only bit 0 of
-// `mismatch` means anything.
+// positions in the window are constants then.
 template <uint32_t PATTERN>
 __device__ __forceinline__ void decode_six_fixed(CodedWindow &in, uint32_t &hist, uint32_t &mismatch)
 {
