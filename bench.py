@@ -151,12 +151,22 @@ def alloc_output(ctx, n_samples, mode, fill, candidates=5, compare=True):
     if mode == "spread" and os.environ.get("BENCH_BACKEND", "nccl") != "nccl":
         mode = "first"                                    # rehearsal with ranks sharing a device: no exclusive use of its memory
     if mode == "spread":
-        t_alloc = time.perf_counter()
-        try:
-            raw, spread = ctx.alloc_spread(n_samples * 8, parts=3)
-        except _lib.OfdmTxError:                          # (e.g. another process took the memory meanwhile)
-            raw, spread = torch.empty(n_samples * 8, dtype=torch.uint8, device=dev), False
-        t_alloc = time.perf_counter() - t_alloc
+        # (a device whose memory a process before has just given back can look full, or hand out memory in
+        #  no order at all, for a few seconds: a second and a third attempt, two seconds apart)
+        attempts = 0
+        while True:
+            attempts += 1
+            t_alloc = time.perf_counter()
+            try:
+                raw, spread = ctx.alloc_spread(n_samples * 8, parts=3)
+            except _lib.OfdmTxError:                      # (e.g. another process took the memory meanwhile)
+                raw, spread = torch.empty(n_samples * 8, dtype=torch.uint8, device=dev), False
+            t_alloc = time.perf_counter() - t_alloc
+            if spread or attempts == 3:
+                break
+            del raw
+            torch.cuda.empty_cache()
+            time.sleep(2.0)
         iq = raw.view(torch.complex64)
         if spread:
             rec = {"mode": "spread", "note": "64 MiB pieces alternating between `parts` of the device memory's three parts, "
@@ -164,7 +174,7 @@ def alloc_output(ctx, n_samples, mode, fill, candidates=5, compare=True):
                                              "= what it held while it looked); one "
                                              "launch timed into it and (unless --placement-compare 0) into an ordinary first "
                                              "allocation, which is freed before the timed region",
-                   "alloc_s": round(t_alloc, 3), "peak_held_GB": round(ctx.last_alloc["peak_held_bytes"] / 1e9, 1),
+                   "alloc_s": round(t_alloc, 3), "attempts": attempts, "peak_held_GB": round(ctx.last_alloc["peak_held_bytes"] / 1e9, 1),
                    "handles": ctx.last_alloc["handles"], "parts": ctx.last_alloc["parts"], "spread_ms": round(once(iq), 3)}
             rec["kept"] = "spread"
             if compare:

@@ -17,9 +17,11 @@
 //      allocation order), 16 GiB at a time, each window mapped as it comes;
 //   2. every new window is timed with itself (its two halves written as a buffer of alternating
 //      64 MiB pieces, the waves spread over all of it) and, as such a buffer, together with a
-//      reference window.  The slowest time of a window with itself is the one-part time; a window
-//      that is faster than that with itself is a mixture of parts (memory that was released in
-//      another order than it was taken) and is left out.  Together with the reference, a window
+//      reference window.  The time of a slow window with itself (the median of those within 10 %
+//      of the slowest, for single times scatter by several per cent while the driver clears what a
+//      process before left) is the one-part time; a window that is faster than that with itself is
+//      a mixture of parts (memory that was released in another order than it was taken) and is
+//      left out.  Together with the reference (the window nearest to the one-part time), a window
 //      of another part is 15-25 % faster than the one-part time, a window of the same part is
 //      not; what falls in between is left out too;
 //   3. the windows that differ from the reference are split once more, against the first of them;
@@ -39,6 +41,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <cmath>
 #include <map>
 #include <mutex>
 #include <new>
@@ -98,13 +101,13 @@ struct Prober {
         if (e0) (void)hipEventDestroy(e0);
         if (e1) (void)hipEventDestroy(e1);
     }
-    // ms for writing `each` pieces at a and `each` pieces at b in alternation (the best of two timed
+    // ms for writing `each` pieces at a and `each` pieces at b in alternation (the best of three timed
     // launches behind an untimed one that touches the pages)
     float pair(void *a, void *b, size_t each = WINDOW)
     {
         const uint32_t n_units = (uint32_t)(2 * each) * UNITS_PER_PIECE;
         float best = 1e30f;
-        for (int rep = 0; rep < 3 && ok; rep++) {
+        for (int rep = 0; rep < 4 && ok; rep++) {
             if (rep) ok = ok && hipEventRecord(e0, nullptr) == hipSuccess;
             hipLaunchKernelGGL(k_probe_pair, dim3(512), dim3(512), 0, nullptr, (float4 *)a, (float4 *)b, n_units);
             if (rep) {
@@ -165,7 +168,7 @@ Built build_spread(int device, size_t pieces, int want_parts)
     h.reserve(max_windows * WINDOW);
     size_t n_mapped = 0;
     bool ok = true;
-    float t_one = 0.f;                                      // the one-part time: the largest `own` seen
+    float t_one = 0.f;                                      // the one-part time (see below)
     int ref0 = -1, ref1 = -1, restarts = 0;                 // the reference, and the first window of another part
     size_t count[3] = {0, 0, 0};
     auto win = [&](size_t w) { return (void *)(pool + w * WINDOW * PIECE); };
@@ -199,21 +202,32 @@ Built build_spread(int device, size_t pieces, int want_parts)
         if (!ok) break;
         // ---- every new window with itself.  A window that lies in one part takes the one-part time; on
         // a device with a history (memory released in another order than it was taken) a window can be
-        // a mixture of parts, is faster with itself, and is left out.  The reference is the slowest
-        // window of the first step; should a later window be clearly slower still, the first step
-        // held mixtures only, and the classification starts over from that window.
+        // a mixture of parts, is faster with itself, and is left out.  The times of one-part windows
+        // scatter by several per cent when the driver is still clearing a previous process's memory,
+        // so the one-part time is not the largest time seen but the median of the step's slow windows
+        // (those within 10 % of the slowest), and the reference is the window nearest to it.  Should a
+        // later step's median be clearly slower still, the first step held mixtures only, and the
+        // classification starts over from that step.
         W.resize(w1);
-        size_t slowest = w0;
+        float slowest = 0.f;
         for (size_t w = w0; w < w1 && ok; w++) {
             W[w].own = 2.f * probe.pair(win(w), (char *)win(w) + WINDOW / 2 * PIECE, WINDOW / 2);
             ok = probe.ok;
-            if (W[w].own > W[slowest].own) slowest = w;
+            slowest = std::max(slowest, W[w].own);
         }
         if (!ok) break;
-        if (ref0 < 0 || (W[slowest].own > 1.07f * t_one && restarts < 2)) {
+        std::vector<float> slow;
+        for (size_t w = w0; w < w1; w++)
+            if (W[w].own >= 0.9f * slowest) slow.push_back(W[w].own);
+        std::sort(slow.begin(), slow.end());
+        const float step_one = slow[slow.size() / 2];
+        if (ref0 < 0 || (step_one > 1.07f * t_one && restarts < 2)) {
             if (ref0 >= 0) restarts++;
-            t_one = W[slowest].own;
-            ref0 = (int)slowest;
+            t_one = step_one;
+            size_t nearest = w0;
+            for (size_t w = w0; w < w1; w++)
+                if (std::fabs(W[w].own - t_one) < std::fabs(W[nearest].own - t_one)) nearest = w;
+            ref0 = (int)nearest;
             ref1 = -1;
             count[0] = count[1] = count[2] = 0;
             for (Win &x : W) x.cls = -2;

@@ -390,3 +390,28 @@ def test_spread_allocation_with_three_parts(txctx):
     assert int(buf[0]) == 5 and int(buf[-1]) == 5 and buf.numel() == 3 << 30
     ptr = C.c_void_p()
     assert txctx._lib.ofdmtx_stream_alloc_parts(txctx._h, 1 << 20, 4, C.byref(ptr), None) == _lib.EINVAL
+
+
+def test_spread_allocation_on_a_device_with_a_history(txctx):
+    """Memory that was taken whole and given back in a random order comes out of the driver in no order:
+    windows of the allocation order are then mixtures of parts or lie in any of them.  The parts are still
+    found (they are measured, not assumed), and the buffer takes stores at the rate of a spread one."""
+    torch.cuda.empty_cache()
+    free0, total = torch.cuda.mem_get_info(txctx.device)
+    if free0 < 0.9 * total:
+        pytest.skip("needs the device to itself")
+    rng = np.random.default_rng(91)
+    n = int((free0 - (40 << 30)) >> 30)
+    held = [torch.empty(1 << 30, dtype=torch.uint8, device=txctx.device) for _ in range(n)]
+    for i in rng.permutation(n):
+        held[i] = None
+        if i % 16 == 0:
+            torch.cuda.empty_cache()                    # back to the driver a few at a time, in that order
+    del held
+    torch.cuda.empty_cache()
+    buf, spread = txctx.alloc_spread(4 << 30)
+    assert spread and txctx.last_alloc["parts"] >= 2
+    buf.fill_(3)
+    torch.cuda.synchronize()
+    assert int(buf[0]) == 3 and int(buf[-1]) == 3
+    del buf
