@@ -359,7 +359,9 @@ def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1,
                     help="ranks = GPUs of this node; > 1 without a launcher's WORLD_SIZE: this process starts them")
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps (default 600: 4.6 s of the headline kernel, long enough for a sampling monitor to see "
+                         "and for the clocks to settle; 20 with --gather 1, whose steps are link-bound)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--packets", type=int, default=1_000_000, help="packets per GPU per step")
     ap.add_argument("--fused", type=int, default=1, help="1: single fused kernel (ofdmtx_tx), 0: two kernels")
@@ -388,6 +390,8 @@ def parse_args(argv=None):
     a = ap.parse_args(argv)
     if a.gpus < 1:
         ap.error("--gpus must be at least 1")
+    if a.steps is None:
+        a.steps = 20 if a.gather else 600
     return a
 
 
