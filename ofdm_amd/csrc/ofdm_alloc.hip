@@ -276,10 +276,14 @@ Built build_spread(int device, size_t pieces, int want_parts)
         int order[3] = {0, 1, 2};
         std::sort(order, order + 3, [&](int x, int y) { return count[x] > count[y]; });
         const int n_cls = (count[order[2]] * WINDOW >= (pieces + 2) / 3) ? 3 : 2;
-        std::vector<size_t> of[3];
+        // (of each class the windows that took longest with themselves first: the least mixed ones)
+        std::vector<size_t> by_time;
         for (size_t w = 0; w < W.size(); w++)
-            if (W[w].cls >= 0)
-                for (size_t k = 0; k < WINDOW; k++) of[W[w].cls].push_back(w * WINDOW + k);
+            if (W[w].cls >= 0) by_time.push_back(w);
+        std::stable_sort(by_time.begin(), by_time.end(), [&](size_t x, size_t y) { return W[x].own > W[y].own; });
+        std::vector<size_t> of[3];
+        for (size_t w : by_time)
+            for (size_t k = 0; k < WINDOW; k++) of[W[w].cls].push_back(w * WINDOW + k);
         size_t next[3] = {0, 0, 0};
         for (size_t i = 0; i < pieces; i++) {
             const int c = order[i % n_cls];
