@@ -6,6 +6,8 @@
   * determinism under the pilot schedule: packets 127 apart with equal payloads give equal IQ
     (the polarity index advances by 58 symbols per packet, modulo 127).
 Mixed-rate ragged batch (all eight rates, payload lengths 1..2304): same checks at 2*10^5 packets.
+Every other rate as a uniform batch of about 3*10^9 samples (24 GB of IQ): fused against two-kernel path,
+the receiver over every packet, sampled packets against the oracle.
 """
 import numpy as np
 import pytest
@@ -122,3 +124,43 @@ def test_config3_mixed_rate_ragged(txctx, c_oracle):
         a = int(lay["sample_off"][i])
         err = rel_l2_rows(iq[a:a + len(want)].cpu().numpy(), want)
         assert err.max() <= REL_L2_TOL, (i, err.max())
+
+
+@pytest.mark.parametrize("regime", range(1, 8))
+def test_uniform_batches_of_the_other_rates(txctx, c_oracle, regime):
+    ln = 1500
+    probe = txctx.plan_uniform(1, regime, ln)
+    per_pkt = probe.n_samples
+    probe.close()
+    n = int(3_000_000_000 // per_pkt)
+    free, _ = torch.cuda.mem_get_info()
+    if free < 2.3 * n * per_pkt * 8:
+        pytest.skip("not enough free HBM")
+    dev = txctx.device
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(40 + regime)
+    payloads = torch.randint(0, 256, (n * ln,), dtype=torch.uint8, device=dev, generator=gen)
+    plan = txctx.plan_uniform(n, regime, ln, pilot_start=regime)
+    iq = plan.tx(payloads)
+    msg = plan.encode_bits(payloads)
+    iq2 = plan.modulate(msg)
+    torch.cuda.synchronize()
+    assert equal_chunked(iq, iq2), "fused kernel differs from encode_bits + modulate"
+    del iq2
+    got, status = plan.loopback(iq)
+    assert int(status.abs().max()) == 0
+    assert equal_chunked(got[:n * ln - (n * ln) % 4], payloads[:n * ln - (n * ln) % 4])
+    del got, status
+    lay = plan.layout()
+    rng = np.random.default_rng(regime)
+    for i in [0, n - 1] + list(rng.integers(0, n, 4)):
+        i = int(i)
+        pl = payloads[i * ln:(i + 1) * ln].cpu().numpy().tobytes()
+        ref = c_oracle.encode_bits(pl, regime)
+        mo, ml = int(lay["msg_off"][i]), int(lay["msg_len"][i])
+        assert msg[mo:mo + ml].cpu().numpy().tobytes() == ref["interleaved"], "packet %d" % i
+        want = c_oracle.modulate(ref["interleaved"], regime, int(lay["pilot_base"][i]), 0.3, 3)["iq64"]
+        a = int(lay["sample_off"][i])
+        err = rel_l2_rows(iq[a:a + len(want)].cpu().numpy(), want)
+        assert err.max() <= REL_L2_TOL, (i, err.max())
+    plan.close()
