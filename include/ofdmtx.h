@@ -306,7 +306,9 @@ int ofdmtx_repeat(ofdmtx_ctx *ctx, const float *d_in, uint64_t period, uint64_t 
  * ofdmtx_rx_demod: d_iq (the plan's n_samples complex64) -> d_coded: per packet the hard
  *   decisions as coded bits in transmit order, at the plan's message offsets (msg_bytes bytes:
  *   the layout and, for a clean loop-back, the content of the d_coded tap of
- *   ofdmtx_encode_bits); d_status[n_pkts] is SET to the OFDMTX_RX_PILOTS / _NULLS bits.
+ *   ofdmtx_encode_bits); d_status[n_pkts] is SET to the OFDMTX_RX_PILOTS / _NULLS bits.  (A ragged
+ *   plan's packets are handed to the waves through a counter of the context's, one of 64 per launch
+ *   in turn: more than 64 such launches in flight on one context at once would share one.)
  * ofdmtx_rx_decode: d_coded -> d_payloads (payload bytes at the plan's payload offsets,
  *   payload_bytes bytes); ORs the remaining bits into d_status (zero it first if
  *   ofdmtx_rx_demod did not write it). */

@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "ofdmtx.h"
 
 // last HIP error of the calling thread (ofdmtx_last_hip_error)
@@ -21,6 +23,7 @@ __attribute__((visibility("hidden"))) extern thread_local int ofdmtx_g_last_hip;
     } while (0)
 
 constexpr int LUT_SIZE = 128;         // constellation LUT slots, see ofdmtx.hip
+constexpr int RX_TURNS = 64;          // launches of ofdmtx_rx_demod on ragged plans that may be in flight on one context
 
 struct DevTables {
     const uint32_t *scr_word;   // 127
@@ -44,6 +47,8 @@ struct ofdmtx_ctx {
     bool gap_nonzero;
     uint8_t *d_static;          // this device's copy of the library's static work area (ofdmtx.hip)
     void *h_pinned;             // 256 page-locked bytes: totals read back by ofdmtx_tx_ragged_static
+    uint32_t *d_turns;          // RX_TURNS packet counters, 64 bytes apart: one per ofdmtx_rx_demod launch in flight (ragged plans)
+    std::atomic<uint32_t> turn; // the next launch's counter
     int n_cu;
     DevTables tables() const;   // defined in ofdmtx.hip
 };

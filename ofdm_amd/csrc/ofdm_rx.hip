@@ -160,7 +160,7 @@ constexpr int RX_TG = 72;              // float2 per symbol in the transposition
 template <bool UNIFORM>
 __global__ void __launch_bounds__(64 * RX_WAVES, 5)
 k_rx_demod(PlanParams P, DevTables T, const float2 *__restrict__ iq, uint8_t *__restrict__ coded,
-           uint32_t *__restrict__ status, uint32_t wave_words)
+           uint32_t *__restrict__ status, uint32_t wave_words, uint32_t *turn)
 {
     extern __shared__ uint32_t s_rxw[];                   // per wave: the packet's coded bits, MSB-first words
     __shared__ v2f s_tw[64];                              // W64^{l p} / (8 amp) at 8 p + l
@@ -203,7 +203,15 @@ k_rx_demod(PlanParams P, DevTables T, const float2 *__restrict__ iq, uint8_t *__
     const uint32_t pre_rows = (P.flags & OFDMTX_F_PREAMBLE)
                                   ? ((P.flags & (OFDMTX_F_PNC_A | OFDMTX_F_PNC_B)) ? 6u : 4u) : 0u;
 
-    for (uint32_t p = blockIdx.x * RX_WAVES + wave; p < P.n_pkts; p += gridDim.x * RX_WAVES) {
+    // Packets of a uniform plan are dealt out in turn; those of a ragged plan (5 to 1400 symbols each) go to
+    // whichever wave is free: `turn` counts them (zero at launch).
+    auto next_packet = [&](uint32_t p) -> uint32_t {
+        if (UNIFORM) return p + gridDim.x * RX_WAVES;
+        uint32_t v = 0;
+        if (lane == 0) v = atomicAdd(turn, 1u);
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+    };
+    for (uint32_t p = UNIFORM ? blockIdx.x * RX_WAVES + wave : next_packet(0u); p < P.n_pkts; p = next_packet(p)) {
         const Pkt k = load_pkt<UNIFORM>(P, p);
         const RegimeInfo ri = regime_info((int)k.regime);
         const size_t row0 = (UNIFORM ? (size_t)p * P.rows_per_pkt : (size_t)P.row_start[p]) + pre_rows;
@@ -571,12 +579,16 @@ int ofdmtx_rx_demod(ofdmtx_ctx *ctx, const ofdmtx_plan *pl, const float *d_iq, u
     if (blocks > cap) blocks = cap;
     const DevTables tab = ctx->tables();
     const float2 *iq = reinterpret_cast<const float2 *>(d_iq);
-    if (pl->pp.uniform)
+    if (pl->pp.uniform) {
         hipLaunchKernelGGL((k_rx_demod<true>), dim3((unsigned)blocks), dim3(64 * RX_WAVES), lds, (hipStream_t)stream,
-                           pl->pp, tab, iq, d_coded, d_status, wave_words);
-    else
+                           pl->pp, tab, iq, d_coded, d_status, wave_words, (uint32_t *)nullptr);
+    } else {
+        // this launch's packet counter: one of RX_TURNS, zeroed on the launch's stream in front of it
+        uint32_t *turn = ctx->d_turns + 16u * (ctx->turn.fetch_add(1u) % (uint32_t)RX_TURNS);
+        HIPCHK(hipMemsetAsync(turn, 0, sizeof(uint32_t), (hipStream_t)stream));
         hipLaunchKernelGGL((k_rx_demod<false>), dim3((unsigned)blocks), dim3(64 * RX_WAVES), lds, (hipStream_t)stream,
-                           pl->pp, tab, iq, d_coded, d_status, wave_words);
+                           pl->pp, tab, iq, d_coded, d_status, wave_words, turn);
+    }
     HIPCHK(hipGetLastError());
     return OFDMTX_OK;
 }

@@ -1809,6 +1809,8 @@ int ofdmtx_create(int device, ofdmtx_ctx **out)
     if (e == hipSuccess) e = hipMalloc(&c->d_crc, tab.size() * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&c->d_xpow8, xp.size() * sizeof(uint32_t));
     if (e == hipSuccess) e = hipHostMalloc(&c->h_pinned, 256, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc(&c->d_turns, RX_TURNS * 64);
+    if (e == hipSuccess) e = hipMemset(c->d_turns, 0, RX_TURNS * 64);
     // this device's copy of the static work area (the device is current: hipSetDevice above)
     if (e == hipSuccess) e = hipGetSymbolAddress(reinterpret_cast<void **>(&c->d_static), HIP_SYMBOL(g_static_area));
     if (e == hipSuccess && device >= 0 && device < MAX_DEVICES) {
@@ -1844,6 +1846,7 @@ int ofdmtx_destroy(ofdmtx_ctx *c)
     if (c->d_crc) (void)hipFree(c->d_crc);
     if (c->d_xpow8) (void)hipFree(c->d_xpow8);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    if (c->d_turns) (void)hipFree(c->d_turns);
     delete c;
     return OFDMTX_OK;
 }
