@@ -130,14 +130,22 @@ def load_traffic(workload_key):
         return None
 
 
-def alloc_output(ctx, n_samples, mode, fill, candidates=5, compare=True):
+def alloc_output(ctx, n_samples, mode, fill, candidates=5, compare=True, inputs=None, move_inputs=True):
     """The output buffer of a workload and a record of how it was placed.  Where a large buffer lies in
     HBM changes the store rate on MI355X (one of the memory's three parts: 5.6-5.7 TB/s, pieces
     alternating between the parts: 7.1 TB/s), so by default the buffer comes from
     TxContext.alloc_spread; one launch into an ordinary first allocation is timed beside it for the
     record.  mode "probe": the fastest of a few ordinary allocations; "first": the first allocation
-    as it comes.  fill(buffer) is the workload's own launch."""
+    as it comes.  fill(buffer) is the workload's own launch.
+    inputs: the workload's input tensor.  With a spread buffer it is moved (unless move_inputs is false) into
+    the tail of the same buffer -- pieces of all parts, like the output: the headline launch reads 1.5 GB
+    beside 48 GB of stores and runs 0.9 % faster with them there (tools/scratch/payload_in_spread.py), the
+    variable-size modulator, a third of whose traffic is reads, 2 %.  The third value returned is the tensor
+    to use from then on (the one passed in where nothing was moved)."""
     dev = ctx.device
+    grain = 64 << 20
+    out_bytes = -(-n_samples * 8 // grain) * grain
+    in_bytes = inputs.numel() * inputs.element_size() if (inputs is not None and move_inputs) else 0
 
     def once(b):
         fill(b)
@@ -158,7 +166,7 @@ def alloc_output(ctx, n_samples, mode, fill, candidates=5, compare=True):
             attempts += 1
             t_alloc = time.perf_counter()
             try:
-                raw, spread = ctx.alloc_spread(n_samples * 8, parts=3)
+                raw, spread = ctx.alloc_spread(out_bytes + in_bytes, parts=3)
             except _lib.OfdmTxError:                      # (e.g. another process took the memory meanwhile)
                 raw, spread = torch.empty(n_samples * 8, dtype=torch.uint8, device=dev), False
             t_alloc = time.perf_counter() - t_alloc
@@ -167,8 +175,12 @@ def alloc_output(ctx, n_samples, mode, fill, candidates=5, compare=True):
             del raw
             torch.cuda.empty_cache()
             time.sleep(2.0)
-        iq = raw.view(torch.complex64)
+        iq = raw[:n_samples * 8].view(torch.complex64)
         if spread:
+            if in_bytes:
+                moved = raw[out_bytes:out_bytes + in_bytes].view(inputs.dtype).view(inputs.shape)
+                moved.copy_(inputs)
+                inputs = moved
             rec = {"mode": "spread", "note": "64 MiB pieces alternating between `parts` of the device memory's three parts, "
                                              "found by timing writes into the memory taken (ofdmtx_stream_alloc; peak_held_GB "
                                              "= what it held while it looked); one "
@@ -177,6 +189,7 @@ def alloc_output(ctx, n_samples, mode, fill, candidates=5, compare=True):
                    "alloc_s": round(t_alloc, 3), "attempts": attempts, "peak_held_GB": round(ctx.last_alloc["peak_held_bytes"] / 1e9, 1),
                    "handles": ctx.last_alloc["handles"], "parts": ctx.last_alloc["parts"], "spread_ms": round(once(iq), 3)}
             rec["kept"] = "spread"
+            rec["inputs"] = "in the tail of the same buffer (pieces of all parts)" if in_bytes else "an ordinary allocation"
             if compare:
                 plain = torch.empty(n_samples, dtype=torch.complex64, device=dev)
                 rec["first_allocation_ms"] = round(once(plain), 3)
@@ -184,7 +197,7 @@ def alloc_output(ctx, n_samples, mode, fill, candidates=5, compare=True):
                     iq, rec["kept"] = plain, "first allocation"
                 del plain
                 torch.cuda.empty_cache()
-            return iq, rec
+            return iq, rec, inputs
         del iq, raw
         mode = "probe"                                    # the device could not provide the layout
     if mode == "probe":
@@ -202,8 +215,8 @@ def alloc_output(ctx, n_samples, mode, fill, candidates=5, compare=True):
         torch.cuda.empty_cache()
         return iq, {"mode": "probe", "candidates_ms": [round(t, 3) for t in times], "chosen": keep,
                     "note": "one launch timed into each candidate buffer (allocation order); the fastest is kept, "
-                            "the others freed before the timed region"}
-    return torch.empty(n_samples, dtype=torch.complex64, device=dev), {"mode": "first"}
+                            "the others freed before the timed region"}, inputs
+    return torch.empty(n_samples, dtype=torch.complex64, device=dev), {"mode": "first"}, inputs
 
 
 def timed_steps(step, a, dist, backend, dev):
@@ -246,7 +259,8 @@ def run_rawofdm(a, ctx, dev, world, rank, dist, backend):
     gen.manual_seed(4 + rank)
     ph = torch.randint(0, 4, (n_frames * size * p.data_tones,), device=dev, generator=gen)
     data = torch.polar(torch.ones_like(ph, dtype=torch.float32), (2 * ph + 1) * (np.pi / 4)).contiguous()   # unit QPSK
-    iq, placement = alloc_output(ctx, plan.n_samples, a.placement, lambda b: plan.modulate(data, out=b), a.placement_candidates, bool(a.placement_compare))
+    iq, placement, data = alloc_output(ctx, plan.n_samples, a.placement, lambda b: plan.modulate(data, out=b), a.placement_candidates,
+                                       bool(a.placement_compare), inputs=data, move_inputs=bool(a.inputs_spread))
 
     def step(events=None):
         if events is not None:
@@ -299,7 +313,8 @@ def run_ragged(a, ctx, dev, world, rank, dist, backend):
     gen = torch.Generator(device=dev)
     gen.manual_seed(3 + rank)
     payloads = torch.randint(0, 256, (int(lens.sum()),), dtype=torch.uint8, device=dev, generator=gen)
-    iq, placement = alloc_output(ctx, plan.n_samples, a.placement, lambda b: plan.tx(payloads, out=b), a.placement_candidates, bool(a.placement_compare))
+    iq, placement, payloads = alloc_output(ctx, plan.n_samples, a.placement, lambda b: plan.tx(payloads, out=b), a.placement_candidates,
+                                           bool(a.placement_compare), inputs=payloads, move_inputs=bool(a.inputs_spread))
 
     def step(events=None):
         if events is not None:
@@ -378,6 +393,9 @@ def parse_args(argv=None):
                     help="output buffer: pieces alternating between the parts of the device memory, the fastest of a "
                          "few ordinary allocations, or the first allocation as it comes")
     ap.add_argument("--placement-candidates", type=int, default=5)
+    ap.add_argument("--inputs-spread", type=int, default=1,
+                    help="1: the workload's input lies in the tail of the spread output buffer (pieces of all parts); "
+                         "0: where the allocator put it")
     ap.add_argument("--placement-compare", type=int, default=1,
                     help="0: no comparison launch into an ordinary allocation (profiler runs: keeps the kernel's average clean)")
     ap.add_argument("--gather", type=int, default=0,
@@ -495,8 +513,9 @@ def main(a):
     msg = plan.alloc_msg() if not gather else None
     iq, placement = None, None
     if not gather:
-        iq, placement = alloc_output(ctx, plan.n_samples, a.placement, lambda b: plan.tx(payloads, out=b, work=msg),
-                                     a.placement_candidates, bool(a.placement_compare))
+        iq, placement, payloads = alloc_output(ctx, plan.n_samples, a.placement, lambda b: plan.tx(payloads, out=b, work=msg),
+                                               a.placement_candidates, bool(a.placement_compare), inputs=payloads,
+                                               move_inputs=bool(a.inputs_spread))
     if gather:
         from ofdm_amd.dist import chunk_bounds, gather_chunked
         spans = chunk_bounds(n, a.gather_chunks if a.gather_chunks > 0 else max(1, -(-n // 12288)))
