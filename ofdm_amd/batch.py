@@ -340,10 +340,20 @@ class TxPlan:
     def alloc_iq(self):
         return torch.empty(self.n_samples, dtype=torch.complex64, device=self.ctx.device)
 
-    def alloc_iq_spread(self, parts=2):
-        """The plan's output buffer from TxContext.alloc_spread: (complex64 tensor, spread)."""
-        t, spread = self.ctx.alloc_spread(self.n_samples * 8, parts)
-        return t.view(torch.complex64), spread
+    def alloc_iq_spread(self, parts=2, input_bytes=0):
+        """The plan's output buffer from TxContext.alloc_spread: (complex64 tensor, spread).
+        input_bytes > 0: the same buffer also holds that many bytes for the caller's input (payloads,
+        messages) behind the output, from a 64 MiB boundary on -- reads are spread over the parts like
+        the stores, which the headline launch rewards with 1.3 % -- and the call returns
+        (complex64 tensor, uint8 tensor, spread)."""
+        grain = 64 << 20
+        out_bytes = self.n_samples * 8
+        if not input_bytes:
+            t, spread = self.ctx.alloc_spread(out_bytes, parts)
+            return t.view(torch.complex64), spread
+        at = -(-out_bytes // grain) * grain
+        t, spread = self.ctx.alloc_spread(at + int(input_bytes), parts)
+        return t[:out_bytes].view(torch.complex64), t[at:at + int(input_bytes)], spread
 
     def alloc_iq_probed(self, fill, max_candidates=5, reserve_bytes=8 << 30, launches=2):
         """An output buffer for a long-lived, repeatedly written stream, placed where the device writes

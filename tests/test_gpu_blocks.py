@@ -415,3 +415,18 @@ def test_spread_allocation_on_a_device_with_a_history(txctx):
     torch.cuda.synchronize()
     assert int(buf[0]) == 3 and int(buf[-1]) == 3
     del buf
+
+
+def test_output_and_input_in_one_spread_buffer(txctx):
+    """TxPlan.alloc_iq_spread(input_bytes=...): the payloads live behind the output in the same buffer; the
+    launch gives the samples it gives from an ordinary allocation."""
+    n, ln = 300, 700
+    plan = txctx.plan_uniform(n, 6, ln)
+    pay = torch.randint(0, 256, (n * ln,), dtype=torch.uint8, device=txctx.device)
+    want = plan.tx(pay)
+    iq, room, spread = plan.alloc_iq_spread(input_bytes=n * ln)
+    assert iq.numel() == plan.n_samples and room.numel() == n * ln and room.data_ptr() % (64 << 20) == iq.data_ptr() % (64 << 20)
+    room.copy_(pay)
+    got = plan.tx(room, out=iq)
+    assert torch.equal(got.view(torch.int64), want.view(torch.int64))
+    plan.close()
